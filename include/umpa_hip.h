@@ -1,0 +1,131 @@
+/*
+ * umpa_hip.h -- C ABI of libumpa_hip.so, the MI355X (gfx950) implementation of the UMPA
+ * per-pixel matching path.
+ *
+ * This is the drop-in boundary.  The reference has exactly one native interface under its
+ * Python API: the C++ class models::ModelBase<double> and its three subclasses
+ * (reference UMPA/lib/Model.h:78-189), bound by Cython in UMPA/Model.pxd:30-68 and driven by
+ * the pixel loop of UMPA/model.pyx:476-492.  Every entry point below names the reference
+ * interface it replaces.  Signatures use plain pointers and sizes only.
+ *
+ * Conventions (all taken from the reference):
+ *  - frames are row-major float64, frame k has shape dims[2k] x dims[2k+1];
+ *  - (i, j) are absolute frame coordinates (row, column); padding is NOT added by
+ *    umpa_hip_cost/min/coverage (UMPA/model.pyx:853-854) but IS added by the *_region calls,
+ *    exactly like the Cython loop adds `offset` (UMPA/model.pyx:482-483);
+ *  - shifts: component 0 = rows, component 1 = columns (UMPA/model.pyx:461-465);
+ *  - values = [f, T, dx(col), dy(row), df] (UMPA/lib/Model.cpp:934-938);
+ *  - status word: bit0 ok, bit1 bound_error, bit2 dimension, bit3 positive
+ *    (UMPA/lib/Optim.h:7-12).
+ *
+ * Every function that returns int returns a status word (>= 0) or a negative error code;
+ * umpa_hip_last_error() then holds a message.  The library never falls back to a CPU path:
+ * with no usable HIP device every call fails with UMPA_HIP_E_DEVICE.
+ */
+#ifndef UMPA_HIP_H
+#define UMPA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMPA_HIP_KIND_NODF      0   /* models::ModelNoDF      Model.h:126-140 */
+#define UMPA_HIP_KIND_DF        1   /* models::ModelDF        Model.h:145-164 */
+#define UMPA_HIP_KIND_DFKERNEL  2   /* models::ModelDFKernel  Model.h:170-189 (not built yet: E_UNSUPPORTED) */
+
+#define UMPA_HIP_ST_OK          1
+#define UMPA_HIP_ST_BOUND       2
+#define UMPA_HIP_ST_DIMENSION   4
+#define UMPA_HIP_ST_POSITIVE    8
+
+#define UMPA_HIP_E_ARG         (-1)
+#define UMPA_HIP_E_DEVICE      (-2)
+#define UMPA_HIP_E_NOMEM       (-3)
+#define UMPA_HIP_E_UNSUPPORTED (-4)
+#define UMPA_HIP_E_LAUNCH      (-5)
+
+/* create flags */
+#define UMPA_HIP_F_DEVICE_FRAMES  1  /* sam/ref/mask pointers are device pointers on `device`; borrowed, not copied */
+/* match flags */
+#define UMPA_HIP_F_DEVICE_IO      1  /* values/uv/err/covermap/debug pointers are device pointers; call is async on `stream` */
+#define UMPA_HIP_F_FORCE_DIRECT   2  /* use the general direct kernel even where the tiled fast path applies */
+#define UMPA_HIP_F_FORCE_TILED    4  /* fail with E_UNSUPPORTED instead of silently using the direct kernel */
+
+typedef struct umpa_hip_model umpa_hip_model;
+
+/* library-wide */
+int         umpa_hip_device_count(void);
+const char *umpa_hip_last_error(void);
+const char *umpa_hip_version(void);
+
+/*
+ * Replaces the ModelNoDF/ModelDF/ModelDFKernel constructors (Model.cpp:193-216, :597-604,
+ * :963-968; called from model.pyx:769, :835, :911).  Host frames are copied to the device
+ * once here and stay resident for the model's lifetime (the reference keeps borrowed host
+ * pointers instead, model.pyx:123-129).  mask may be NULL.  pos is [Na][2], >= 0.
+ * Returns NULL on error.
+ */
+umpa_hip_model *umpa_hip_create(int kind, int Na, const int *dims,
+                                double *const *sam, double *const *ref, double *const *mask,
+                                const int *pos, int Nw, const double *win,
+                                int max_shift, int padding, int device, int flags);
+
+/* ~ModelBase (Model.cpp:224) */
+void umpa_hip_destroy(umpa_hip_model *m);
+
+/* ModelBase::set_window (Model.cpp:239-246); negative Nw -> UMPA_HIP_E_ARG (the reference throws) */
+int umpa_hip_set_window(umpa_hip_model *m, const double *win, int Nw);
+/* ModelBase::subpx_func (Model.h:91; model.pyx:753-755): -1 spline, 0 none, 1 paraboloid */
+int umpa_hip_set_subpx(umpa_hip_model *m, int mode);
+/* ModelBase::reference_shift (Model.h:92; model.pyx:732-742): 0 'sam', 1 'ref' */
+int umpa_hip_set_reference_shift(umpa_hip_model *m, int v);
+
+/* ModelBase::coverage (Model.cpp:273-314), one pixel */
+int umpa_hip_coverage(umpa_hip_model *m, double *out, int i, int j);
+/* the serial double loop of model.pyx:524-528, as one launch; out is host [N0*N1] */
+int umpa_hip_coverage_region(umpa_hip_model *m, int start0, int step0, int N0,
+                             int start1, int step1, int N1, double *out);
+
+/* Model*::cost_interface (Model.cpp:533-542, :887-897): values[0]=cost, [1]=T, [2]=df */
+int umpa_hip_cost(umpa_hip_model *m, int i, int j, int shift_i, int shift_j, double *values);
+
+/* Model*::min (Model.cpp:562-578, :923-940) with the minimizer_debug fields (Optim.h:15-21)
+ * returned separately; uv is in/out (start shift -> result).  dbg_* may be NULL. */
+int umpa_hip_min(umpa_hip_model *m, int i, int j, double *values, double *uv,
+                 double *dbg_d, double *dbg_a, int *ncalls);
+
+/*
+ * The pixel loop of model.pyx:476-492 as one call: for xi < N0, xj < N1 run min() at
+ * (padding+start0+step0*xi, padding+start1+step1*xj) unless covermap[xi,xj] < cover_threshold.
+ *   values [N0*N1*nparam] in/out, uv [N0*N1*2] in/out, err [N0*N1] out (status.ok),
+ *   covermap [N0*N1] or NULL, dbg_d [N0*N1*25] / dbg_a [N0*N1*16] / dbg_ncalls [N0*N1] or NULL.
+ * With UMPA_HIP_F_DEVICE_IO all of these are device pointers and the call only enqueues work
+ * on `stream` (a hipStream_t, or NULL for the default stream).
+ */
+int umpa_hip_match_region(umpa_hip_model *m, int start0, int step0, int N0,
+                          int start1, int step1, int N1,
+                          double *values, int nparam, double *uv, int *err,
+                          const double *covermap, double cover_threshold,
+                          double *dbg_d, double *dbg_a, int *dbg_ncalls,
+                          int flags, void *stream);
+
+/* sub-pixel fits, exposed by the reference as model.spmq / model.spm (model.pyx:31-80):
+ * spmin (Optim.cpp:41-130) and spmin_quad (Optim.cpp:155-185), evaluated on the device. */
+int umpa_hip_spmin(int device, const double *a16, double *pos2, double *value);
+int umpa_hip_spmin_quad(int device, const double *a16, double *pos2, double *value);
+
+/* instrumentation used by bench.py for the roofline line: when enabled every kernel launch is
+ * bracketed by HIP events on its launch stream; collect() waits for them and folds them into
+ * per-kernel totals (returns the number of distinct kernels), read() returns one total. */
+int umpa_hip_timing_enable(umpa_hip_model *m, int on);
+int umpa_hip_timing_collect(umpa_hip_model *m);
+int umpa_hip_timing_read(umpa_hip_model *m, int index, const char **name, double *total_ms, int *launches);
+/* which path the last match_region took: 0 none, 1 direct, 2 tiled */
+int umpa_hip_last_path(umpa_hip_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMPA_HIP_H */

@@ -1,0 +1,212 @@
+// umpa_direct.h -- the general ("direct") matching kernel: one lane per output pixel, the
+// windowed multi-frame cost evaluated by an explicit window x frame sum straight from the
+// frames in HBM/L2, exactly the arithmetic of the reference cost functions
+// (UMPA/lib/Model.cpp:359-509 NoDF, :631-862 DF), including masks, per-frame positions
+// (sample stepping), unequal frame shapes and both coordinate conventions.
+//
+// It is the path for everything the tiled fast path (umpa_tiled.h) does not cover, and the
+// first-principles cross-check for it.  All 64 lanes of a wave evaluate their cost together
+// (the window/frame loops have wave-uniform trip counts); only the cheap walk bookkeeping
+// diverges.  Window weights and frame descriptors are wave-uniform and come in through
+// scalar loads.
+#pragma once
+#include "umpa_walk.h"
+
+namespace umpa {
+
+struct FrameDesc {
+    const double* sam;
+    const double* ref;
+    const double* mask;   // NULL when the model has no masks
+    int H, W;             // frame shape            (ModelBase::dim, Model.h:86)
+    int pi, pj;           // frame position >= 0    (ModelBase::pos, Model.h:87)
+};
+
+struct ModelDev {
+    const FrameDesc* frames;   // [Na], device
+    const double* win;         // (2Nw+1)^2, device (ModelBase::win, Model.h:88)
+    double win_sum;            // sum of win in row-major order (the `denom` of Model.cpp:724-739)
+    int Na, Nw, ms, padding;
+    int subpx, ref_mode;
+};
+
+struct RegionArgs {
+    int org0, step0, N0;       // pixel (xi,xj) sits at frame coords (org0+step0*xi, org1+step1*xj)
+    int org1, step1, N1;
+    double* values; int nparam;
+    double* uv;                // may be NULL: start at (0,0), result not stored
+    int* err;
+    const double* cover; double thr;
+    double* dbg_d; double* dbg_a; int* dbg_n;
+};
+
+__device__ __forceinline__ double pair_weight(double a, double b)   // Utils.cpp:125-130
+{
+    return a * b / (a + b + 1e-8);
+}
+
+// One cost evaluation at pixel (i,j), shift (si rows, sj cols).  KIND: 0 NoDF, 1 DF.
+template <int KIND, bool MASK>
+__device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int si, int sj,
+                                           double& cost, Fit& fit)
+{
+    const int ms = m.ms;
+    // Model.cpp:372-399 / :654-681 (flags are asymmetric in the reference; kept)
+    if (si <= -ms || si >= ms) return UMPA_ST_BOUND;
+    if (sj <= -ms) return UMPA_ST_BOUND | UMPA_ST_DIM;
+    if (sj >= ms) return UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
+
+    int ri = i, rj = j, qi = i, qj = j;                  // Model.cpp:408-421 / :688-701
+    if (m.ref_mode) { qi -= si; qj -= sj; } else { ri += si; rj += sj; }
+
+    const int Nw = m.Nw, S = 2 * Nw + 1, pad = m.padding;
+    double t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    double wt = MASK ? 0.0 : (double)m.Na;               // Model.cpp:425,:711 / :463,:777
+
+    for (int k = 0; k < m.Na; k++) {
+        const FrameDesc f = m.frames[k];
+        const int li = i - f.pi, lj = j - f.pj;          // Model.cpp:430-433 / :716-719
+        if (li - pad < 0 || li + pad > f.H || lj - pad < 0 || lj + pad > f.W) continue;
+        const size_t ro = (size_t)(ri - f.pi - Nw) * f.W + (rj - f.pj - Nw);
+        const size_t qo = (size_t)(qi - f.pi - Nw) * f.W + (qj - f.pj - Nw);
+        const double* __restrict__ R = f.ref + ro;
+        const double* __restrict__ Q = f.sam + qo;
+        const double* __restrict__ MR = MASK ? f.mask + ro : nullptr;
+        const double* __restrict__ MQ = MASK ? f.mask + qo : nullptr;
+
+        double s2 = 0, s4 = 0, s6 = 0, sm = 0;
+        for (int a = 0; a < S; a++) {
+            const double* wrow = m.win + a * S;
+            const size_t off = (size_t)a * f.W;
+            for (int b = 0; b < S; b++) {
+                double w = wrow[b];
+                const double r = R[off + b];
+                const double q = Q[off + b];
+                if (MASK) {
+                    if (KIND == 1) sm += w * r;          // the ref mean is never mask-weighted (Model.cpp:804)
+                    w *= pair_weight(MR[off + b], MQ[off + b]);
+                    wt += w;
+                    s2 += w;
+                }
+                const double wq = w * q, wr = w * r;
+                t1 += wq * q;
+                t3 += wr * r;
+                t5 += wr * q;
+                if (KIND == 1) { s4 += wq; s6 += wr; }
+            }
+        }
+        if (KIND == 1) {                                 // Model.cpp:739,:770-772 / :808,:843-845
+            const double mean = (MASK ? sm : s6) / m.win_sum;
+            t2 += MASK ? mean * mean * s2 : mean * mean;
+            t4 += mean * s4;
+            t6 += mean * s6;
+        }
+    }
+
+    if (KIND == 1) {                                     // Model.cpp:849-858
+        const double det = t2 * t3 - t6 * t6;
+        const double K = (t2 * t5 - t4 * t6) / det;
+        const double beta = (t3 * t4 - t5 * t6) / det;
+        fit.t = beta + K;
+        fit.v = K / fit.t;
+        cost = (t1 + beta * beta * t2 + K * K * t3 - 2 * beta * t4 - 2 * K * t5 + 2 * beta * K * t6) / wt;
+    } else {                                             // Model.cpp:502-505
+        fit.t = t5 / t3;
+        fit.v = 0.0;
+        cost = (t1 - t5 * fit.t) / wt;
+    }
+    return UMPA_ST_OK;
+}
+
+// Store one pixel's results the way Model*::min + the Cython loop do
+// (Model.cpp:573-577 / :934-938; model.pyx:487-491).
+__device__ __forceinline__ void store_pixel(const RegionArgs& A, size_t px, int kind, const Walk& w,
+                                            const double* memo, const double* nb)
+{
+    double* v = A.values + px * A.nparam;
+    v[0] = w.out;
+    v[1] = w.live.t;
+    v[2] = w.uv1;
+    v[3] = w.uv0;
+    if (kind == 1) v[4] = w.live.v;
+    if (A.uv) { A.uv[2 * px] = w.uv0; A.uv[2 * px + 1] = w.uv1; }
+    A.err[px] = w.status & UMPA_ST_OK;
+    if (A.dbg_n) A.dbg_n[px] = w.n;
+    if (A.dbg_d) for (int q = 0; q < 25; q++) A.dbg_d[px * 25 + q] = memo[q];
+    if (A.dbg_a) for (int q = 0; q < 16; q++) A.dbg_a[px * 16 + q] = nb[q];
+}
+
+// blockIdx -> tile remap so that each XCD (blocks b, b+8, ... share one) works on a
+// contiguous band of tile rows and keeps the halo rows of neighbouring tiles in its own L2.
+__device__ __forceinline__ int xcd_band_remap(int lin, int total)
+{
+    const int per = (total + 7) >> 3;
+    return (lin & 7) * per + (lin >> 3);
+}
+
+#define UMPA_DIRECT_BX 64
+#define UMPA_DIRECT_BY 4
+
+template <int KIND, bool MASK>
+__global__ void __launch_bounds__(UMPA_DIRECT_BX* UMPA_DIRECT_BY)
+match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
+{
+    const int lin = xcd_band_remap(blockIdx.x, nbx * nby);
+    if (lin >= nbx * nby) return;
+    const int bx = lin % nbx, by = lin / nbx;
+    const int xj = bx * UMPA_DIRECT_BX + threadIdx.x;
+    const int xi = by * UMPA_DIRECT_BY + threadIdx.y;
+    if (xi >= A.N0 || xj >= A.N1) return;
+    const size_t px = (size_t)xi * A.N1 + xj;
+    if (A.cover && A.cover[px] < A.thr) return;          // model.pyx:480-481: skipped pixels keep their zeros
+
+    const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
+    double memo[25], nb[16];
+    for (int q = 0; q < 16; q++) nb[q] = 0.0;
+    Walk w;
+    walk_begin(w, memo, A.uv ? A.uv[2 * px] : 0.0, A.uv ? A.uv[2 * px + 1] : 0.0);
+    while (w.phase != PH_DONE) {
+        double c = 0.0;
+        Fit fit = w.live;
+        const int st = eval_direct<KIND, MASK>(m, i, j, w.req_i, w.req_j, c, fit);
+        walk_feed(w, memo, nb, st, c, fit, m.subpx);
+    }
+    store_pixel(A, px, KIND, w, memo, nb);
+}
+
+// Model*::cost_interface for one pixel (Model.cpp:533-542, :887-897): out = [cost, T, df, status]
+template <int KIND, bool MASK>
+__global__ void cost_one_kernel(ModelDev m, int i, int j, int si, int sj, double* out)
+{
+    double c = 0.0;
+    Fit fit = {0.0, 0.0};
+    const int st = eval_direct<KIND, MASK>(m, i, j, si, sj, c, fit);
+    out[0] = c; out[1] = fit.t; out[2] = fit.v; out[3] = (double)st;
+}
+
+// ModelBase::coverage over a region (Model.cpp:273-314 inside the loop of model.pyx:524-528)
+__global__ void coverage_kernel(ModelDev m, int org0, int step0, int N0, int org1, int step1, int N1,
+                                int has_mask, double* out)
+{
+    const int xj = blockIdx.x * blockDim.x + threadIdx.x;
+    const int xi = blockIdx.y * blockDim.y + threadIdx.y;
+    if (xi >= N0 || xj >= N1) return;
+    const int i = org0 + step0 * xi, j = org1 + step1 * xj, pad = m.padding;
+    double c = 0.0;
+    for (int k = 0; k < m.Na; k++) {
+        const FrameDesc f = m.frames[k];
+        const int li = i - f.pi, lj = j - f.pj;
+        if (li - pad < 0 || li + pad > f.H || lj - pad < 0 || lj + pad > f.W) continue;
+        c += has_mask ? f.mask[(size_t)li * f.W + lj] : 1.0;
+    }
+    out[(size_t)xi * N1 + xj] = c;
+}
+
+__global__ void spfit_kernel(const double* a, double* io, int quad)
+{
+    double x = io[0], y = io[1];
+    io[2] = quad ? spmin_quad(a, x, y) : spmin(a, x, y);
+    io[0] = x; io[1] = y;
+}
+
+} // namespace umpa

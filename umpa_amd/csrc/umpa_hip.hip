@@ -1,0 +1,563 @@
+// umpa_hip.hip -- libumpa_hip.so: C ABI (include/umpa_hip.h) + kernel launches.  gfx950 only.
+//
+// There is no CPU fallback in this library: every entry point needs a HIP device and fails
+// loudly (negative code + umpa_hip_last_error()) without one.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+#include "../../include/umpa_hip.h"
+#include "umpa_walk.h"
+#include "umpa_direct.h"
+#include "umpa_tiled.h"
+
+using namespace umpa;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return fail(code, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {                       // grow-only device scratch
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return -1; }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct TimedLaunch { int name; hipEvent_t t0, t1; };
+
+} // namespace
+
+struct umpa_hip_model {
+    int kind = 0, Na = 0, Nw = 0, ms = 0, padding = 0, subpx = -1, ref_mode = 0;
+    int device = 0;
+    bool has_mask = false, owns_frames = true;
+    std::vector<int> dims, pos;
+    std::vector<double*> d_sam, d_ref, d_mask;     // device frame pointers
+    void* d_frames_blob = nullptr;                 // one allocation holding all owned frames
+    FrameDesc* d_desc = nullptr;
+    double* d_win = nullptr;
+    std::vector<double> win;
+    double win_sum = 0.0;
+    hipStream_t stream = nullptr;                  // used by the host-I/O entry points
+    DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small;
+    TiledState tiled;                              // scratch of the tiled fast path
+    int last_path = 0;
+    bool timing = false;
+    std::vector<TimedLaunch> launches;
+    std::vector<hipEvent_t> event_pool;
+    std::vector<std::string> tnames;
+    std::vector<double> tms;
+    std::vector<int> tcount;
+
+    ModelDev dev() const
+    {
+        ModelDev d;
+        d.frames = d_desc; d.win = d_win; d.win_sum = win_sum;
+        d.Na = Na; d.Nw = Nw; d.ms = ms; d.padding = padding; d.subpx = subpx; d.ref_mode = ref_mode;
+        return d;
+    }
+};
+
+namespace {
+
+const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk"};
+enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4 };
+
+hipEvent_t get_event(umpa_hip_model* m)
+{
+    if (!m->event_pool.empty()) { hipEvent_t e = m->event_pool.back(); m->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct ScopedTimer {                   // brackets a launch with events when timing is enabled
+    umpa_hip_model* m; hipStream_t s; TimedLaunch tl; bool on;
+    ScopedTimer(umpa_hip_model* m_, hipStream_t s_, int name) : m(m_), s(s_), on(m_->timing)
+    {
+        if (!on) return;
+        tl.name = name; tl.t0 = get_event(m); tl.t1 = get_event(m);
+        if (!tl.t0 || !tl.t1) { on = false; return; }
+        (void)hipEventRecord(tl.t0, s);
+    }
+    ~ScopedTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(tl.t1, s);
+        m->launches.push_back(tl);
+    }
+};
+
+int upload_win(umpa_hip_model* m, const double* win, int Nw)
+{
+    const int S = 2 * Nw + 1;
+    m->win.assign(win, win + (size_t)S * S);
+    double s = 0.0;
+    for (int n = 0; n < S * S; n++) s += win[n];     // row-major order, as Model.cpp:725-736
+    m->win_sum = s;
+    if (m->d_win) (void)hipFree(m->d_win);
+    m->d_win = nullptr;
+    HIP_TRY(hipMalloc((void**)&m->d_win, (size_t)S * S * sizeof(double)), UMPA_HIP_E_NOMEM);
+    HIP_TRY(hipMemcpy(m->d_win, win, (size_t)S * S * sizeof(double), hipMemcpyHostToDevice), UMPA_HIP_E_DEVICE);
+    m->Nw = Nw;
+    return 0;
+}
+
+int check_region(const umpa_hip_model* m, int start0, int step0, int N0, int start1, int step1, int N1)
+{
+    if (N0 <= 0 || N1 <= 0 || step0 <= 0 || step1 <= 0 || start0 < 0 || start1 < 0)
+        return fail(UMPA_HIP_E_ARG, "bad region start/step/N (%d,%d,%d ; %d,%d,%d)", start0, step0, N0, start1, step1, N1);
+    // extent = max(pos+shape) - 2*padding  (model.pyx:531-549)
+    int e0 = 0, e1 = 0;
+    for (int k = 0; k < m->Na; k++) {
+        e0 = std::max(e0, m->pos[2 * k] + m->dims[2 * k]);
+        e1 = std::max(e1, m->pos[2 * k + 1] + m->dims[2 * k + 1]);
+    }
+    e0 -= 2 * m->padding; e1 -= 2 * m->padding;
+    if (start0 + (long)step0 * (N0 - 1) >= e0 || start1 + (long)step1 * (N1 - 1) >= e1)
+        return fail(UMPA_HIP_E_ARG, "region exceeds the reconstructible extent %d x %d", e0, e1);
+    return 0;
+}
+
+template <int KIND, bool MASK>
+void launch_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
+{
+    const int nbx = (A.N1 + UMPA_DIRECT_BX - 1) / UMPA_DIRECT_BX;
+    const int nby = (A.N0 + UMPA_DIRECT_BY - 1) / UMPA_DIRECT_BY;
+    const int total = nbx * nby;
+    const int grid = ((total + 7) / 8) * 8;          // multiple of 8 so the XCD band remap covers every tile
+    ScopedTimer t(m, s, KN_DIRECT);
+    hipLaunchKernelGGL((match_direct_kernel<KIND, MASK>), dim3(grid), dim3(UMPA_DIRECT_BX, UMPA_DIRECT_BY), 0, s,
+                       m->dev(), A, nbx, nby);
+}
+
+int run_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
+{
+    if (m->kind == UMPA_HIP_KIND_NODF) { if (m->has_mask) launch_direct<0, true>(m, A, s); else launch_direct<0, false>(m, A, s); }
+    else { if (m->has_mask) launch_direct<1, true>(m, A, s); else launch_direct<1, false>(m, A, s); }
+    HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
+    m->last_path = 1;
+    return 0;
+}
+
+// Can the tiled fast path take this region?  (see umpa_tiled.h for what it covers)
+bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
+{
+    if (m->has_mask) return false;
+    for (int k = 0; k < m->Na; k++) {
+        if (m->pos[2 * k] || m->pos[2 * k + 1]) return false;
+        if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
+    }
+    if (A.step0 != 1 || A.step1 != 1) return false;
+    if (A.cover) return false;                        // with pos == 0 and no mask coverage == Na everywhere
+    if (A.uv) return false;                           // caller-supplied start shifts: direct kernel
+    return tiled_supported(m->Nw, m->ms, m->Na);
+}
+
+int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s)
+{
+    const bool can_tile = tiled_applicable(m, A);
+    if ((flags & UMPA_HIP_F_FORCE_TILED) && !can_tile)
+        return fail(UMPA_HIP_E_UNSUPPORTED, "tiled path does not cover this model/region");
+    if (can_tile && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
+        TiledTimers tt;
+        int rc = tiled_match(m->tiled, m->dev(), m->kind, m->dims[0], m->dims[1], A, s,
+                             m->timing ? &tt : nullptr);
+        if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
+        if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
+        if (m->timing) {
+            for (int q = 0; q < tt.n; q++) { TimedLaunch tl; tl.name = tt.name[q]; tl.t0 = tt.t0[q]; tl.t1 = tt.t1[q]; m->launches.push_back(tl); }
+        }
+        m->last_path = 2;
+        return 0;
+    }
+    return run_direct(m, A, s);
+}
+
+} // namespace
+
+extern "C" {
+
+int umpa_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* umpa_hip_last_error(void) { return g_err.c_str(); }
+const char* umpa_hip_version(void) { return "umpa_hip 0.1 (gfx950)"; }
+
+umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const* sam, double* const* ref,
+                                double* const* mask, const int* pos, int Nw, const double* win,
+                                int max_shift, int padding, int device, int flags)
+{
+    if (kind != UMPA_HIP_KIND_NODF && kind != UMPA_HIP_KIND_DF) {
+        fail(UMPA_HIP_E_UNSUPPORTED, "model kind %d is not built in the HIP library yet", kind);
+        return nullptr;
+    }
+    if (Na <= 0 || !dims || !sam || !ref || !pos || !win || Nw < 0 || max_shift < 0 || padding < Nw + max_shift) {
+        fail(UMPA_HIP_E_ARG, "bad arguments to umpa_hip_create (Na=%d Nw=%d max_shift=%d padding=%d)", Na, Nw, max_shift, padding);
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fail(UMPA_HIP_E_DEVICE, "no HIP device available (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { fail(UMPA_HIP_E_ARG, "device %d out of range (%d devices)", device, ndev); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(UMPA_HIP_E_DEVICE, "hipSetDevice(%d) failed", device); return nullptr; }
+
+    umpa_hip_model* m = new (std::nothrow) umpa_hip_model;
+    if (!m) { fail(UMPA_HIP_E_NOMEM, "out of host memory"); return nullptr; }
+    m->kind = kind; m->Na = Na; m->ms = max_shift; m->padding = padding; m->device = device;
+    m->has_mask = mask != nullptr;
+    m->owns_frames = !(flags & UMPA_HIP_F_DEVICE_FRAMES);
+    m->dims.assign(dims, dims + 2 * Na);
+    m->pos.assign(pos, pos + 2 * Na);
+    for (int k = 0; k < Na; k++) {
+        if (dims[2 * k] <= 0 || dims[2 * k + 1] <= 0 || pos[2 * k] < 0 || pos[2 * k + 1] < 0) {
+            fail(UMPA_HIP_E_ARG, "frame %d: bad shape or negative position", k);
+            delete m;
+            return nullptr;
+        }
+    }
+    bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
+
+    m->d_sam.resize(Na); m->d_ref.resize(Na); m->d_mask.assign(Na, nullptr);
+    if (ok && m->owns_frames) {
+        size_t total = 0;
+        for (int k = 0; k < Na; k++) total += (size_t)dims[2 * k] * dims[2 * k + 1];
+        const size_t nstacks = m->has_mask ? 3 : 2;
+        ok = hipMalloc(&m->d_frames_blob, total * nstacks * sizeof(double)) == hipSuccess;
+        if (!ok) fail(UMPA_HIP_E_NOMEM, "cannot allocate %zu bytes for the frame stacks", total * nstacks * sizeof(double));
+        double* base = (double*)m->d_frames_blob;
+        size_t off = 0;
+        for (int k = 0; ok && k < Na; k++) {
+            const size_t n = (size_t)dims[2 * k] * dims[2 * k + 1];
+            m->d_sam[k] = base + off;
+            m->d_ref[k] = base + total + off;
+            ok = hipMemcpyAsync(m->d_sam[k], sam[k], n * sizeof(double), hipMemcpyHostToDevice, m->stream) == hipSuccess &&
+                 hipMemcpyAsync(m->d_ref[k], ref[k], n * sizeof(double), hipMemcpyHostToDevice, m->stream) == hipSuccess;
+            if (ok && m->has_mask) {
+                m->d_mask[k] = base + 2 * total + off;
+                ok = hipMemcpyAsync(m->d_mask[k], mask[k], n * sizeof(double), hipMemcpyHostToDevice, m->stream) == hipSuccess;
+            }
+            off += n;
+        }
+        if (ok) ok = hipStreamSynchronize(m->stream) == hipSuccess;
+        if (!ok && g_err.empty()) fail(UMPA_HIP_E_DEVICE, "frame upload failed: %s", hipGetErrorString(hipGetLastError()));
+    } else if (ok) {
+        for (int k = 0; k < Na; k++) { m->d_sam[k] = sam[k]; m->d_ref[k] = ref[k]; if (m->has_mask) m->d_mask[k] = mask[k]; }
+    }
+    if (ok) {
+        std::vector<FrameDesc> desc(Na);
+        for (int k = 0; k < Na; k++) {
+            desc[k].sam = m->d_sam[k]; desc[k].ref = m->d_ref[k]; desc[k].mask = m->d_mask[k];
+            desc[k].H = dims[2 * k]; desc[k].W = dims[2 * k + 1]; desc[k].pi = pos[2 * k]; desc[k].pj = pos[2 * k + 1];
+        }
+        ok = hipMalloc((void**)&m->d_desc, Na * sizeof(FrameDesc)) == hipSuccess &&
+             hipMemcpy(m->d_desc, desc.data(), Na * sizeof(FrameDesc), hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) fail(UMPA_HIP_E_NOMEM, "cannot allocate the frame descriptor table");
+    }
+    if (ok) ok = upload_win(m, win, Nw) == 0;
+    if (!ok) { umpa_hip_destroy(m); return nullptr; }
+    return m;
+}
+
+void umpa_hip_destroy(umpa_hip_model* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (auto& l : m->launches) { (void)hipEventDestroy(l.t0); (void)hipEventDestroy(l.t1); }
+    for (auto e : m->event_pool) (void)hipEventDestroy(e);
+    tiled_release(m->tiled);
+    m->b_values.release(); m->b_uv.release(); m->b_err.release(); m->b_cover.release();
+    m->b_dd.release(); m->b_da.release(); m->b_dn.release(); m->b_small.release();
+    if (m->d_desc) (void)hipFree(m->d_desc);
+    if (m->d_win) (void)hipFree(m->d_win);
+    if (m->d_frames_blob) (void)hipFree(m->d_frames_blob);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int umpa_hip_set_window(umpa_hip_model* m, const double* win, int Nw)
+{
+    if (!m || !win) return fail(UMPA_HIP_E_ARG, "null argument");
+    if (Nw < 0) return fail(UMPA_HIP_E_ARG, "Nw must be non-negative.");           // Model.cpp:242
+    // The reference does not re-derive the padding when the window grows (model.pyx:702-704) and
+    // then reads outside the frames.  Refuse that instead of faulting the GPU.
+    if (Nw + m->ms > m->padding)
+        return fail(UMPA_HIP_E_ARG, "Nw=%d with max_shift=%d exceeds the padding %d fixed at construction", Nw, m->ms, m->padding);
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    return upload_win(m, win, Nw);
+}
+
+int umpa_hip_set_subpx(umpa_hip_model* m, int mode)
+{
+    if (!m) return fail(UMPA_HIP_E_ARG, "null model");
+    m->subpx = mode;
+    return 0;
+}
+
+int umpa_hip_set_reference_shift(umpa_hip_model* m, int v)
+{
+    if (!m) return fail(UMPA_HIP_E_ARG, "null model");
+    m->ref_mode = v ? 1 : 0;
+    return 0;
+}
+
+int umpa_hip_coverage_region(umpa_hip_model* m, int start0, int step0, int N0, int start1, int step1, int N1, double* out)
+{
+    if (!m || !out) return fail(UMPA_HIP_E_ARG, "null argument");
+    if (int rc = check_region(m, start0, step0, N0, start1, step1, N1)) return rc;
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    const size_t n = (size_t)N0 * N1;
+    if (m->b_cover.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "coverage buffer");
+    dim3 blk(64, 4), grd((N1 + 63) / 64, (N0 + 3) / 4);
+    {
+        ScopedTimer t(m, m->stream, KN_COVER);
+        hipLaunchKernelGGL(coverage_kernel, grd, blk, 0, m->stream, m->dev(), m->padding + start0, step0, N0,
+                           m->padding + start1, step1, N1, (int)m->has_mask, (double*)m->b_cover.p);
+    }
+    HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
+    HIP_TRY(hipMemcpyAsync(out, m->b_cover.p, n * sizeof(double), hipMemcpyDeviceToHost, m->stream), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipStreamSynchronize(m->stream), UMPA_HIP_E_DEVICE);
+    return UMPA_HIP_ST_OK;
+}
+
+int umpa_hip_coverage(umpa_hip_model* m, double* out, int i, int j)
+{
+    if (!m || !out) return fail(UMPA_HIP_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    if (m->b_small.reserve(64 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
+    hipLaunchKernelGGL(coverage_kernel, dim3(1), dim3(1), 0, m->stream, m->dev(), i, 1, 1, j, 1, 1, (int)m->has_mask, (double*)m->b_small.p);
+    HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
+    HIP_TRY(hipMemcpyAsync(out, m->b_small.p, sizeof(double), hipMemcpyDeviceToHost, m->stream), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipStreamSynchronize(m->stream), UMPA_HIP_E_DEVICE);
+    return UMPA_HIP_ST_OK;
+}
+
+static int pixel_in_frames(const umpa_hip_model* m, int i, int j)
+{
+    // a single-pixel call must keep every window inside the frames that cover the pixel; pixels no frame
+    // covers are harmless (all frames skipped).  Only reject coordinates that could index before a frame.
+    (void)m; (void)i; (void)j;
+    return 1;
+}
+
+int umpa_hip_cost(umpa_hip_model* m, int i, int j, int si, int sj, double* values)
+{
+    if (!m || !values) return fail(UMPA_HIP_E_ARG, "null argument");
+    (void)pixel_in_frames;
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    if (m->b_small.reserve(64 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
+    double* d = (double*)m->b_small.p;
+    const ModelDev dv = m->dev();
+    if (m->kind == 0) { if (m->has_mask) hipLaunchKernelGGL((cost_one_kernel<0, true>), 1, 1, 0, m->stream, dv, i, j, si, sj, d);
+                        else hipLaunchKernelGGL((cost_one_kernel<0, false>), 1, 1, 0, m->stream, dv, i, j, si, sj, d); }
+    else { if (m->has_mask) hipLaunchKernelGGL((cost_one_kernel<1, true>), 1, 1, 0, m->stream, dv, i, j, si, sj, d);
+           else hipLaunchKernelGGL((cost_one_kernel<1, false>), 1, 1, 0, m->stream, dv, i, j, si, sj, d); }
+    HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
+    double h[4];
+    HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipStreamSynchronize(m->stream), UMPA_HIP_E_DEVICE);
+    const int st = (int)h[3];
+    if (st & UMPA_HIP_ST_OK) {                 // on a bound error the reference leaves values[0] untouched
+        values[0] = h[0];
+        values[1] = h[1];
+        if (m->kind == 1) values[2] = h[2];
+    } else {
+        values[1] = 0.0;                       // args.t / args.v as constructed (Model.cpp:538-541, :892-895)
+        if (m->kind == 1) values[2] = 0.0;
+    }
+    return st;
+}
+
+int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int start1, int step1, int N1,
+                          double* values, int nparam, double* uv, int* err,
+                          const double* covermap, double cover_threshold,
+                          double* dbg_d, double* dbg_a, int* dbg_ncalls, int flags, void* stream)
+{
+    if (!m || !values || !err) return fail(UMPA_HIP_E_ARG, "null argument");
+    if (nparam < (m->kind == 1 ? 5 : 4)) return fail(UMPA_HIP_E_ARG, "nparam=%d too small for this model", nparam);
+    if (int rc = check_region(m, start0, step0, N0, start1, step1, N1)) return rc;
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    const size_t n = (size_t)N0 * N1;
+
+    RegionArgs A;
+    A.org0 = m->padding + start0; A.step0 = step0; A.N0 = N0;       // model.pyx:482-483
+    A.org1 = m->padding + start1; A.step1 = step1; A.N1 = N1;
+    A.nparam = nparam; A.thr = cover_threshold;
+
+    if (flags & UMPA_HIP_F_DEVICE_IO) {
+        A.values = values; A.uv = uv; A.err = err; A.cover = covermap;
+        A.dbg_d = dbg_d; A.dbg_a = dbg_a; A.dbg_n = dbg_ncalls;
+        if (int rc = run_match(m, A, flags, (hipStream_t)stream)) return rc;
+        return UMPA_HIP_ST_OK;
+    }
+
+    hipStream_t s = m->stream;
+    if (m->b_values.reserve(n * nparam * sizeof(double)) || m->b_err.reserve(n * sizeof(int)))
+        return fail(UMPA_HIP_E_NOMEM, "output buffers (%zu pixels)", n);
+    // values and err start from the caller's arrays (zeros in the reference, model.pyx:455,468)
+    HIP_TRY(hipMemcpyAsync(m->b_values.p, values, n * nparam * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipMemcpyAsync(m->b_err.p, err, n * sizeof(int), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+    A.values = (double*)m->b_values.p; A.err = (int*)m->b_err.p;
+    A.uv = nullptr; A.cover = nullptr; A.dbg_d = nullptr; A.dbg_a = nullptr; A.dbg_n = nullptr;
+    if (uv) {
+        if (m->b_uv.reserve(n * 2 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "uv buffer");
+        HIP_TRY(hipMemcpyAsync(m->b_uv.p, uv, n * 2 * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+        A.uv = (double*)m->b_uv.p;
+    }
+    if (covermap) {
+        if (m->b_cover.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "coverage buffer");
+        HIP_TRY(hipMemcpyAsync(m->b_cover.p, covermap, n * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+        A.cover = (const double*)m->b_cover.p;
+    }
+    if (dbg_d) { if (m->b_dd.reserve(n * 25 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_d buffer");
+                 HIP_TRY(hipMemsetAsync(m->b_dd.p, 0, n * 25 * sizeof(double), s), UMPA_HIP_E_DEVICE); A.dbg_d = (double*)m->b_dd.p; }
+    if (dbg_a) { if (m->b_da.reserve(n * 16 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_a buffer");
+                 HIP_TRY(hipMemsetAsync(m->b_da.p, 0, n * 16 * sizeof(double), s), UMPA_HIP_E_DEVICE); A.dbg_a = (double*)m->b_da.p; }
+    if (dbg_ncalls) { if (m->b_dn.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "debug_Ncalls buffer");
+                      HIP_TRY(hipMemsetAsync(m->b_dn.p, 0, n * sizeof(int), s), UMPA_HIP_E_DEVICE); A.dbg_n = (int*)m->b_dn.p; }
+
+    if (int rc = run_match(m, A, flags, s)) return rc;
+
+    HIP_TRY(hipMemcpyAsync(values, A.values, n * nparam * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipMemcpyAsync(err, A.err, n * sizeof(int), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
+    if (uv) HIP_TRY(hipMemcpyAsync(uv, A.uv, n * 2 * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
+    if (dbg_d) HIP_TRY(hipMemcpyAsync(dbg_d, A.dbg_d, n * 25 * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
+    if (dbg_a) HIP_TRY(hipMemcpyAsync(dbg_a, A.dbg_a, n * 16 * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
+    if (dbg_ncalls) HIP_TRY(hipMemcpyAsync(dbg_ncalls, A.dbg_n, n * sizeof(int), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), UMPA_HIP_E_DEVICE);
+    return UMPA_HIP_ST_OK;
+}
+
+int umpa_hip_min(umpa_hip_model* m, int i, int j, double* values, double* uv, double* dbg_d, double* dbg_a, int* ncalls)
+{
+    if (!m || !values) return fail(UMPA_HIP_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    const int np = m->kind == 1 ? 5 : 4;
+    if (m->b_small.reserve(64 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
+    double* d = (double*)m->b_small.p;                 // [0..4] values, [5..6] uv, [7] err(int), [8] ncalls(int), [9..33] d, [34..49] a
+    double h[50];
+    memset(h, 0, sizeof(h));
+    for (int q = 0; q < np; q++) h[q] = values[q];
+    if (uv) { h[5] = uv[0]; h[6] = uv[1]; }
+    hipStream_t s = m->stream;
+    HIP_TRY(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+    RegionArgs A;
+    A.org0 = i; A.step0 = 1; A.N0 = 1; A.org1 = j; A.step1 = 1; A.N1 = 1;      // Model::min takes absolute coordinates
+    A.values = d; A.nparam = np; A.uv = d + 5; A.err = (int*)(d + 7); A.cover = nullptr; A.thr = 0.0;
+    A.dbg_n = (int*)(d + 8); A.dbg_d = d + 9; A.dbg_a = d + 34;
+    if (int rc = run_direct(m, A, s)) return rc;
+    HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s), UMPA_HIP_E_DEVICE);
+    for (int q = 0; q < np; q++) values[q] = h[q];
+    if (uv) { uv[0] = h[5]; uv[1] = h[6]; }
+    int e, nc;
+    memcpy(&e, &h[7], sizeof(int));
+    memcpy(&nc, &h[8], sizeof(int));
+    if (ncalls) *ncalls = nc;
+    if (dbg_d) memcpy(dbg_d, h + 9, 25 * sizeof(double));
+    if (dbg_a) memcpy(dbg_a, h + 34, 16 * sizeof(double));
+    return e;          // only the ok bit survives the region kernel, as in the Cython loop (model.pyx:487)
+}
+
+static int spfit(int device, const double* a16, double* pos2, double* value, int quad)
+{
+    if (!a16 || !pos2 || !value) return fail(UMPA_HIP_E_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(UMPA_HIP_E_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device), UMPA_HIP_E_DEVICE);
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 19 * sizeof(double)), UMPA_HIP_E_NOMEM);
+    double h[19];
+    memcpy(h, a16, 16 * sizeof(double));
+    h[16] = pos2[0]; h[17] = pos2[1]; h[18] = 0.0;
+    hipError_t e = hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(spfit_kernel, 1, 1, 0, 0, d, d + 16, quad); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "spfit: %s", hipGetErrorString(e));
+    pos2[0] = h[16]; pos2[1] = h[17]; *value = h[18];
+    return UMPA_HIP_ST_OK;
+}
+
+int umpa_hip_spmin(int device, const double* a16, double* pos2, double* value) { return spfit(device, a16, pos2, value, 0); }
+int umpa_hip_spmin_quad(int device, const double* a16, double* pos2, double* value) { return spfit(device, a16, pos2, value, 1); }
+
+int umpa_hip_timing_enable(umpa_hip_model* m, int on)
+{
+    if (!m) return fail(UMPA_HIP_E_ARG, "null model");
+    m->timing = on != 0;
+    return 0;
+}
+
+/* Synchronise all recorded launches, fold them into per-kernel totals and return the number of distinct kernels. */
+int umpa_hip_timing_collect(umpa_hip_model* m)
+{
+    if (!m) return fail(UMPA_HIP_E_ARG, "null model");
+    (void)hipSetDevice(m->device);
+    m->tnames.clear(); m->tms.clear(); m->tcount.clear();
+    for (auto& l : m->launches) {
+        float ms = 0.f;
+        if (hipEventSynchronize(l.t1) == hipSuccess && hipEventElapsedTime(&ms, l.t0, l.t1) == hipSuccess) {
+            const char* nm = KERNEL_NAMES[l.name];
+            size_t q = 0;
+            for (; q < m->tnames.size(); q++) if (m->tnames[q] == nm) break;
+            if (q == m->tnames.size()) { m->tnames.push_back(nm); m->tms.push_back(0.0); m->tcount.push_back(0); }
+            m->tms[q] += ms; m->tcount[q] += 1;
+        }
+        m->event_pool.push_back(l.t0); m->event_pool.push_back(l.t1);
+    }
+    m->launches.clear();
+    return (int)m->tnames.size();
+}
+
+int umpa_hip_timing_read(umpa_hip_model* m, int index, const char** name, double* total_ms, int* launches)
+{
+    if (!m || index < 0 || index >= (int)m->tnames.size()) return fail(UMPA_HIP_E_ARG, "bad timing index");
+    if (name) *name = m->tnames[index].c_str();
+    if (total_ms) *total_ms = m->tms[index];
+    if (launches) *launches = m->tcount[index];
+    return 0;
+}
+
+int umpa_hip_last_path(umpa_hip_model* m) { return m ? m->last_path : 0; }
+
+} // extern "C"

@@ -1,0 +1,314 @@
+// umpa_walk.h -- per-pixel minimiser (integer descent + sub-pixel fit) for gfx950.
+//
+// The reference runs one blocking C++ routine per pixel (UMPA/lib/Optim.cpp:233-479) that
+// calls the cost function wherever it needs a value.  On the GPU the cost evaluation is the
+// expensive, wave-convergent part, so the walk is written here as a *resumable* machine: it
+// posts the next shift it needs (`req_i`, `req_j`), the caller evaluates (or looks up) the
+// cost for all active lanes together, and `walk_feed` consumes the value and advances to the
+// next request.  The sequence of requests, the tie rules, the memo handling, the hard
+// restart with stale fit parameters and every early exit are those of the reference; the
+// trajectory (err, Ncalls, integer minimum) is bit-identical by construction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define UMPA_ST_OK        1
+#define UMPA_ST_BOUND     2
+#define UMPA_ST_DIM       4
+#define UMPA_ST_POSITIVE  8
+
+#define UMPA_CALL_CAP 500          // Optim.cpp:14
+#define UMPA_TIE      1e-8         // Optim.cpp:243
+
+namespace umpa {
+
+struct Fit { double t, v; };       // the CostArgs payload (Model.h:29-52)
+
+enum Phase { PH_CENTRE = 0, PH_LO = 1, PH_HI = 2, PH_GATHER = 3, PH_DONE = 4 };
+
+struct Walk {
+    int ci, cj;        // integer centre of the 5x5 memo
+    int req_i, req_j;  // shift whose cost is wanted next
+    int axis;          // 0: columns (west/east), 1: rows
+    int found0, found1;
+    int n;             // cost calls so far (minimizer_debug::Ncalls)
+    int phase;
+    int g;             // gather cursor 0..15
+    int ip, jp;        // quadrant of the 4x4 neighbourhood
+    int lo_up;
+    int status;
+    Fit live, kept;    // *args and args_copy of Optim.cpp:249,265
+    double out, uv0, uv1;
+};
+
+// ---------------------------------------------------------------- sub-pixel fits
+
+// Optim.cpp:41-130.  a[4*row+col] are control points of a uniform bicubic B-spline on
+// {-1,0,1,2}^2; Newton-Raphson on its gradient, <= 21 steps, unclamped.  c[4q+p] is the
+// coefficient of x^p y^q (x = row coordinate), times 36.
+__device__ inline double spmin(const double* a, double& px, double& py)
+{
+    // B[m][p]: coefficient of t^p of cubic B-spline basis function m, times 6
+    const double B[4][4] = {{1, -3, 3, -1}, {4, 0, -6, 3}, {1, 3, 3, -3}, {0, 0, 0, 1}};
+    double c[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        // row-combine first: e[p][s] = sum_r a[r][s] B[r][p]; then c[q][p] = sum_s e[p][s] B[s][q]
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                double e = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) e += a[4 * r + s] * B[r][p];
+                acc += e * B[s][q];
+            }
+            c[4 * q + p] = acc;
+        }
+    }
+    double x = px, y = py;
+    double g[4], g1[4], g2[4];
+    for (int it = 0; it <= 20; it++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double c0 = c[4 * q], c1 = c[4 * q + 1], c2 = c[4 * q + 2], c3 = c[4 * q + 3];
+            g[q] = c0 + x * (c1 + x * (c2 + x * c3));
+            g1[q] = c1 + x * (2 * c2 + x * 3 * c3);
+            g2[q] = 2 * c2 + 6 * c3 * x;
+        }
+        const double fx = g1[0] + y * (g1[1] + y * (g1[2] + y * g1[3]));
+        const double fxx = g2[0] + y * (g2[1] + y * (g2[2] + y * g2[3]));
+        const double fy = g[1] + y * (2 * g[2] + y * 3 * g[3]);
+        const double fxy = g1[1] + y * (2 * g1[2] + y * 3 * g1[3]);
+        const double fyy = 2 * g[2] + 6 * g[3] * y;
+        const double det = fxx * fyy - fxy * fxy;
+        const double dx = (fxy * fy - fyy * fx) / det;
+        const double dy = (fxy * fx - fxx * fy) / det;
+        x += dx;
+        y += dy;
+        if (dx * dx + dy * dy < 1e-8) break;
+    }
+    px = x;
+    py = y;
+#pragma unroll
+    for (int q = 0; q < 4; q++) g[q] = c[4 * q] + x * (c[4 * q + 1] + x * (c[4 * q + 2] + x * c[4 * q + 3]));
+    return (g[0] + y * (g[1] + y * (g[2] + y * g[3]))) / 36.0;
+}
+
+// Optim.cpp:155-185.  Least-squares paraboloid c0 + gi i + gj j + cii i^2 + cij ij + cjj j^2 on
+// {-1,0,1,2}^2: the integer table is 400*pinv(design) (derivation: oracle/umpa_oracle.c
+// quad_init and tests/test_oracle_golden.py).  The vertex pairs (cii,gj) and (cjj,gi) as the
+// reference does (Optim.cpp:180-181).
+__device__ inline double spmin_quad(const double* a, double& px, double& py)
+{
+    // 400*pinv(design), design columns [1, i, j, i^2, ij, j^2] on i,j in {-1,0,1,2}:
+    //   constant row C0 and row-gradient row GI are tabulated (4x4, [row][col]); the
+    //   column-gradient row is GI transposed; the quadratic rows have closed forms
+    //   25*(i^2-i-1), 4*(2i-1)(2j-1), 25*(j^2-j-1).
+    const int C0[16] = {14, 48, 32, -34, 48, 86, 74, 12, 32, 74, 66, 8, -34, 12, 8, -46};
+    const int GI[16] = {-73, -61, -49, -37, 9, 13, 17, 21, 41, 37, 33, 29, 23, 11, -1, -13};
+    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+        const int r = n >> 2, s = n & 3;
+        const int i = r - 1, j = s - 1;
+        const double v = a[n];
+        p0 += C0[n] * v;
+        p1 += GI[n] * v;
+        p2 += GI[4 * s + r] * v;
+        p3 += (25 * (i * i - i - 1)) * v;
+        p4 += (4 * (2 * i - 1) * (2 * j - 1)) * v;
+        p5 += (25 * (j * j - j - 1)) * v;
+    }
+    const double det = 4 * p3 * p5 - p4 * p4;
+    px = -(2 * p3 * p2 - p4 * p1) / det;
+    py = -(2 * p5 * p1 - p4 * p2) / det;
+    return (p0 + 0.5 * (p2 * px + p1 * py)) / 400.0;
+}
+
+// ---------------------------------------------------------------- the walk
+
+__device__ inline void walk_begin(Walk& w, double* memo, double u0, double u1)
+{
+#pragma unroll
+    for (int q = 0; q < 25; q++) memo[q] = -1.0;               // Optim.cpp:252
+    w.ci = (int)round(u0);                                      // Optim.cpp:258-259
+    w.cj = (int)round(u1);
+    w.req_i = w.ci;
+    w.req_j = w.cj;
+    w.axis = 0;
+    w.found0 = w.found1 = 0;
+    w.n = 0;
+    w.phase = PH_CENTRE;
+    w.g = 0;
+    w.ip = w.jp = 0;
+    w.lo_up = 0;
+    w.status = 0;
+    w.live.t = w.live.v = 0.0;                                  // Model.cpp:68,74
+    w.kept = w.live;
+    w.out = 0.0;                                                // `D` is uninitialised in the reference (Model.cpp:566,927)
+    w.uv0 = u0;
+    w.uv1 = u1;
+}
+
+__device__ inline void memo_shift(double* d, int axis, int dir)
+{
+    // Optim.cpp:436-470: the centre moved by `dir` along `axis`; cells that scroll in are unknown
+    if (axis) {
+        if (dir > 0) {
+            for (int q = 5; q < 25; q++) d[q - 5] = d[q];
+            for (int q = 20; q < 25; q++) d[q] = -1.0;
+        } else {
+            for (int q = 24; q >= 5; q--) d[q] = d[q - 5];
+            for (int q = 0; q < 5; q++) d[q] = -1.0;
+        }
+    } else {
+        if (dir > 0) {
+            for (int r = 0; r < 5; r++) {
+                for (int c = 0; c < 4; c++) d[5 * r + c] = d[5 * r + c + 1];
+                d[5 * r + 4] = -1.0;
+            }
+        } else {
+            for (int r = 0; r < 5; r++) {
+                for (int c = 4; c > 0; c--) d[5 * r + c] = d[5 * r + c - 1];
+                d[5 * r] = -1.0;
+            }
+        }
+    }
+}
+
+// Deliver the result of the pending request (status `st`, cost `val`, fit parameters `fit`)
+// and advance to the next request or to PH_DONE.
+__device__ inline void walk_feed(Walk& w, double* memo, double* nb, int st, double val, Fit fit, int subpx)
+{
+    enum { PC_CHECK, PC_LO, PC_HI, PC_DECIDE, PC_GATHER };
+    w.n++;                                                      // Ncalls counts failed calls too (Optim.cpp:263-264)
+    if (!(st & UMPA_ST_OK)) {                                   // any failed call returns at once, outputs as they stand
+        w.status = st;
+        w.phase = PH_DONE;
+        return;
+    }
+    w.live = fit;
+    int pc = PC_CHECK, hi_up = 0;
+    switch (w.phase) {
+    case PH_CENTRE:                                             // Optim.cpp:262-265
+        memo[12] = val;
+        w.kept = w.live;
+        pc = PC_CHECK;
+        break;
+    case PH_LO:                                                 // Optim.cpp:287-297
+        memo[w.axis ? 7 : 11] = val;
+        w.lo_up = val > memo[12] + UMPA_TIE;
+        if (!w.lo_up) w.kept = w.live;
+        pc = PC_HI;
+        break;
+    case PH_HI:                                                 // Optim.cpp:320-328
+        memo[w.axis ? 17 : 13] = val;
+        hi_up = val > memo[12] - UMPA_TIE;
+        if (!hi_up) w.kept = w.live;
+        pc = PC_DECIDE;
+        break;
+    default: {                                                  // PH_GATHER, Optim.cpp:353-378
+        const int r = w.g >> 2, c = w.g & 3;
+        nb[w.g] = val;
+        memo[5 * (w.ip + r) + w.jp + c] = val;
+        if (val < memo[12]) {                                   // missed a lower value: hard restart
+            w.ci += w.ip + r - 2;
+            w.cj += w.jp + c - 2;
+            for (int q = 0; q < 25; q++) memo[q] = -1.0;
+            memo[12] = val;
+            w.live = w.kept;                                    // stale on purpose (Optim.cpp:373)
+            w.found0 = w.found1 = 0;
+            pc = PC_LO;                                         // `goto start` skips the call-cap test
+        } else {
+            w.g++;
+            pc = PC_GATHER;
+        }
+    } break;
+    }
+
+    for (;;) {
+        const int lo = w.axis ? 7 : 11, hi = w.axis ? 17 : 13;
+        if (pc == PC_CHECK) {                                   // while(Ncalls < MAX_CALLS), Optim.cpp:267
+            if (w.n >= UMPA_CALL_CAP) {
+                w.status = st & ~UMPA_ST_OK;                    // Optim.cpp:477
+                w.phase = PH_DONE;
+                return;
+            }
+            pc = PC_LO;
+        }
+        if (pc == PC_LO) {
+            if (memo[lo] < -0.5) {
+                w.phase = PH_LO;
+                w.req_i = w.ci - (w.axis ? 1 : 0);
+                w.req_j = w.cj - (w.axis ? 0 : 1);
+                return;
+            }
+            w.lo_up = memo[lo] > memo[12] + UMPA_TIE;            // Optim.cpp:300
+            pc = PC_HI;
+        }
+        if (pc == PC_HI) {
+            if (memo[hi] < -0.5) {
+                w.phase = PH_HI;
+                w.req_i = w.ci + (w.axis ? 1 : 0);
+                w.req_j = w.cj + (w.axis ? 0 : 1);
+                return;
+            }
+            hi_up = memo[hi] > memo[12] - UMPA_TIE;              // Optim.cpp:331
+            pc = PC_DECIDE;
+        }
+        if (pc == PC_DECIDE) {
+            if (w.lo_up && hi_up) {                             // Optim.cpp:334-417
+                const int f = memo[lo] < memo[hi] ? -1 : 1;
+                if (w.axis) w.found1 = f; else w.found0 = f;
+                const int other = w.axis ? w.found0 : w.found1;
+                if (!other) {
+                    w.axis ^= 1;
+                    pc = PC_CHECK;
+                    continue;
+                }
+                w.ip = memo[17] < memo[7] ? 1 : 0;              // Optim.cpp:344-345
+                w.jp = memo[13] < memo[11] ? 1 : 0;
+                w.g = 0;
+                pc = PC_GATHER;
+            } else {                                            // Optim.cpp:420-474
+                w.uv0 = w.ci;
+                w.uv1 = w.cj;
+                w.out = memo[12];
+                int up = w.lo_up;
+                if (!hi_up && !w.lo_up) up = memo[hi] < memo[lo];
+                const int dir = up ? 1 : -1;
+                if (w.axis) w.ci += dir; else w.cj += dir;
+                memo_shift(memo, w.axis, dir);
+                if (w.axis) w.found0 = 0; else w.found1 = 0;
+                pc = PC_CHECK;
+                continue;
+            }
+        }
+        // PC_GATHER: fill the 4x4 neighbourhood from the memo, asking for what is missing
+        while (w.g < 16) {
+            const int r = w.g >> 2, c = w.g & 3;
+            const double known = memo[5 * (w.ip + r) + w.jp + c];
+            if (known < -0.9) {
+                w.phase = PH_GATHER;
+                w.req_i = w.ci + w.ip + r - 2;
+                w.req_j = w.cj + w.jp + c - 2;
+                return;
+            }
+            nb[w.g] = known;
+            w.g++;
+        }
+        w.live = w.kept;                                        // Optim.cpp:386
+        double x = 1.0 - w.ip, y = 1.0 - w.jp;                  // Optim.cpp:395-396
+        if (subpx == 0) w.out = x;                              // Optim.cpp:399
+        else if (subpx == 1) w.out = spmin_quad(nb, x, y);
+        else w.out = spmin(nb, x, y);
+        w.uv0 = x + (w.ci + w.ip - 1.0);                        // Optim.cpp:407-408
+        w.uv1 = y + (w.cj + w.jp - 1.0);
+        w.status = st;
+        w.phase = PH_DONE;
+        return;
+    }
+}
+
+} // namespace umpa
