@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""
+bench.py -- output-map Mpixels/s of the UMPA matching path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2]
+
+One "step" is one pass of the hot path (`umpa_hip_match_region`, include/umpa_hip.h) over one
+synthetic stack: every output pixel of the frame is matched.  Inputs are resident in HBM before
+the timed region starts; outputs stay in HBM (the PCIe-inclusive rate of the host-array API is
+quoted in DESIGN.md, never here).  N = 1 runs BASELINE config C2 (2048x2048, 10 frames, Nw=5,
+max_shift=5, dark-field on).  N > 1 (launched by torch.distributed.run, one rank per GPU)
+row-shards a virtual (N*2048)-row image: every rank matches its own slab (+halo rows, which a
+host that owns the arrays delivers with the slab) -- no data-path collective, weak scaling.
+
+Rank 0 prints ONE JSON line (see the driver contract), including
+  "roofline":     dominant kernel, algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
+  "cpu_baseline": the reference C++ core (oracle/_ref, kind "reference") or this repo's C
+                  restatement (kind "port") timed on the host cores on a bounded row sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6     # 256 CU x 64 FMA/clk x 2.4 GHz x 2 (not in the guide; public spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--rows", type=int, default=0, help="override frame height (debugging)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force", choices=["auto", "direct", "tiled"], default="auto")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(K, H, W, N0, N1, nparam):
+    """compulsory HBM traffic of one match, fp64."""
+    return 2 * K * H * W * 8 + (8 * nparam + 4) * N0 * N1
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from umpa_amd import _lib, model
+    from umpa_amd.synth import CONFIGS, make_stack
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1 and args.gpus == 1, \
+        "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = dict(CONFIGS[args.config])
+    if args.rows:
+        cfg["H"] = args.rows
+    H, W, K, Nw, ms, df = cfg["H"], cfg["W"], cfg["K"], cfg["Nw"], cfg["max_shift"], cfg["df"]
+    nparam = 5 if df else 4
+
+    # every rank owns one slab (with its halo rows) of a virtual (world*H)-row image
+    t_gen = time.time()
+    sam, ref, _ = make_stack(H, W, K, ms, df=df, seed=100 * rank)
+    t_gen = time.time() - t_gen
+    cls = model.UMPAModelDF if df else model.UMPAModelNoDF
+    m = cls(sam, ref, window_size=Nw, max_shift=ms, device=local)      # H2D happens here, outside the timed region
+    lib, h = m._lib, m._handle
+    N0, N1 = m.extent
+    npx = N0 * N1
+    values = torch.zeros((N0, N1, nparam), dtype=torch.float64, device=dev)
+    err = torch.zeros((N0, N1), dtype=torch.int32, device=dev)
+    ncalls = torch.zeros((N0, N1), dtype=torch.int32, device=dev)
+    flags = _lib.F_DEVICE_IO | {"auto": 0, "direct": _lib.F_FORCE_DIRECT, "tiled": _lib.F_FORCE_TILED}[args.force]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(with_ncalls=False):
+        rc = lib.match_region(h, 0, 1, N0, 0, 1, N1, values.data_ptr(), nparam, None, err.data_ptr(),
+                              None, 0.0, None, None, ncalls.data_ptr() if with_ncalls else None, flags,
+                              ctypes.c_void_p(stream))
+        lib.check(rc, "match_region")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.timing_enable(h, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    lib.timing_enable(h, 0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # per-kernel durations from HIP events recorded on the launch stream during the timed region
+    kernels = {}
+    for q in range(lib.timing_collect(h)):
+        name, tot, cnt = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int()
+        lib.timing_read(h, q, ctypes.byref(name), ctypes.byref(tot), ctypes.byref(cnt))
+        kernels[name.value.decode()] = (tot.value / max(cnt.value, 1), cnt.value)
+    path = {1: "direct", 2: "tiled"}.get(lib.last_path(h), "?")
+
+    step(with_ncalls=True)                                  # untimed: evaluation-count statistics of this dataset
+    torch.cuda.synchronize()
+    nc = ncalls.cpu().numpy()
+    err_h = err.cpu().numpy()
+    vals_h = values.cpu().numpy()
+
+    if rank == 0:
+        dom = max(kernels, key=lambda k: kernels[k][0] * kernels[k][1]) if kernels else None
+        abytes = algorithmic_bytes(K, H, W, N0, N1, nparam)
+        roof = None
+        if dom:
+            # the dominant kernel is charged the whole match's algorithmic bytes ("Roofline accounting")
+            launches_per_step = kernels[dom][1] / args.steps
+            dur_ms = kernels[dom][0] * launches_per_step     # per step
+            ach = abytes / (dur_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(args.config, {}).get(dom)
+                except Exception:
+                    traffic = None
+            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
+                        kernel_ms=round(dur_ms, 4), algorithmic_bytes=abytes,
+                        kernels_ms={k: round(v[0] * v[1] / args.steps, 4) for k, v in kernels.items()})
+            # the path is fp64-FMA bound, not HBM bound: also price the as-written
+            # reference arithmetic (E*K*S^2*c flop per pixel) against the fp64 vector peak
+            c = 15 if df else 8
+            flops = float(nc.mean()) * K * (2 * Nw + 1) ** 2 * c * npx
+            roof["fp64_as_written"] = dict(achieved_tflops=round(flops / (dur_ms * 1e-3) / 1e12, 2),
+                                           peak_tflops=FP64_VECTOR_PEAK_TF,
+                                           note="reference flop count / kernel time; the tiled path does far fewer flops")
+
+        cpu = None
+        if not args.no_cpu and world == 1:
+            cpu = cpu_baseline(sam, ref, Nw, ms, df, N1, vals_h, err_h, nc)
+
+        out = {
+            "metric": "Mpixels/s (output map) at Nw=%d, max_shift=%d, %d frames" % (Nw, ms, K),
+            "value": round(world * npx * args.steps / dt / 1e6, 3),
+            "unit": "Mpx/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d, %d frames, Nw=%d, max_shift=%d, dark-field %s%s" % (
+                           args.config, H, W, K, Nw, ms, "on" if df else "off",
+                           "" if world == 1 else "; row-sharded, one such slab per GPU"),
+                       "output_pixels_per_gpu": npx, "kernel_path": path,
+                       "Ncalls_mean": round(float(nc.mean()), 3), "Ncalls_p99": int(np.percentile(nc, 99)),
+                       "err_ok_fraction": round(float(err_h.mean()), 5), "parallelism": "rows x%d" % world,
+                       "input_generation_s": round(t_gen, 1)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sam, ref, Nw, ms, df, N1, vals_gpu, err_gpu, nc_gpu, target_s=15.0):
+    """Time the CPU checker on a bounded sample of the SAME workload (first rows of the output map)."""
+    from oracle import cpu_model
+    kind = "reference" if cpu_model.have_ref() else "port"
+    ns = cpu_model.ref if kind == "reference" else cpu_model.port
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cls = ns.UMPAModelDF if df else ns.UMPAModelNoDF
+    cm = cls(sam, ref, window_size=Nw, max_shift=ms)
+    cm.debug = True
+
+    def run(rows):
+        t = time.perf_counter()
+        r = cm.match(ROI=((0, rows, 1), (0, N1, 1)), num_threads=cores, quiet=True)
+        return time.perf_counter() - t, r
+
+    rows = max(cores, 16)
+    t1, r = run(rows)
+    rows2 = int(min(cm.extent[0], max(rows, rows * target_s / max(t1, 1e-3))))
+    if rows2 > rows * 1.5:
+        rows = rows2
+        t1, r = run(rows)
+    # sanity: the GPU result on the same rows must agree with what was just timed
+    same_err = bool(np.array_equal(r["err"], err_gpu[:rows]))
+    same_nc = bool(np.array_equal(r["debug_Ncalls"], nc_gpu[:rows]))
+    ok = r["err"] == 1
+    dT = float(np.max(np.abs(r["T"] - vals_gpu[:rows, :, 1])[ok])) if ok.any() else 0.0
+    return dict(value=round(rows * N1 / t1 / 1e6, 5), unit="Mpx/s", cores=cores, kind=kind,
+                sample="first %d of the output rows (%d px), %.1f s, OpenMP dynamic over rows as model.pyx:476-478" % (
+                    rows, rows * N1, t1),
+                gpu_agrees=dict(err=same_err, Ncalls=same_nc, max_abs_dT=dT))
+
+
+if __name__ == "__main__":
+    main()

@@ -101,10 +101,28 @@ class Native:
 _hip = None
 
 
+def _pin_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64; if both that copy
+    and /opt/rocm's get loaded, the second one sees no device and streams / device pointers cannot be
+    shared.  When torch is installed, load ITS runtime first (by path, so the order of `import torch`
+    and of this call does not matter): libumpa_hip.so's DT_NEEDED libamdhip64.so.7 then resolves to
+    the already-loaded object.  A host without torch (C, C++, cgo ...) simply gets /opt/rocm's."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def hip():
     """The product library.  Raises if it is not built; never substitutes anything else."""
     global _hip
     if _hip is None:
+        _pin_hip_runtime()
         _hip = Native(HIP_LIB_PATH, "umpa_hip_", True)
     return _hip
 
