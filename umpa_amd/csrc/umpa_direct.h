@@ -148,7 +148,7 @@ __device__ __forceinline__ int xcd_band_remap(int lin, int total)
 #define UMPA_DIRECT_BY 4
 
 template <int KIND, bool MASK>
-__global__ void __launch_bounds__(UMPA_DIRECT_BX* UMPA_DIRECT_BY)
+__global__ void __launch_bounds__(UMPA_DIRECT_BX* UMPA_DIRECT_BY, 4)
 match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
 {
     const int lin = xcd_band_remap(blockIdx.x, nbx * nby);

@@ -9,6 +9,9 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <cstdlib>
+#include <cmath>
+#include <algorithm>
 
 #include "../../include/umpa_hip.h"
 #include "umpa_walk.h"
@@ -130,6 +133,7 @@ int upload_win(umpa_hip_model* m, const double* win, int Nw)
     HIP_TRY(hipMalloc((void**)&m->d_win, (size_t)S * S * sizeof(double)), UMPA_HIP_E_NOMEM);
     HIP_TRY(hipMemcpy(m->d_win, win, (size_t)S * S * sizeof(double), hipMemcpyHostToDevice), UMPA_HIP_E_DEVICE);
     m->Nw = Nw;
+    tiled_factor_window(m->tiled, win, Nw);
     return 0;
 }
 
@@ -179,8 +183,9 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
     }
     if (A.step0 != 1 || A.step1 != 1) return false;
-    if (A.cover) return false;                        // with pos == 0 and no mask coverage == Na everywhere
-    if (A.uv) return false;                           // caller-supplied start shifts: direct kernel
+    // the region must keep every window inside the frames even for the partial tiles' halo reads: guaranteed
+    // by check_region + clamped staging.  Separable window required (always true for the Hamming window).
+    if (!m->tiled.separable || m->tiled.sep_nw != m->Nw) return false;
     return tiled_supported(m->Nw, m->ms, m->Na);
 }
 

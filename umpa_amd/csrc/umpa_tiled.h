@@ -1,10 +1,610 @@
-// umpa_tiled.h -- tiled fast path (placeholder until the kernels land).
+// umpa_tiled.h -- the tiled fast path for the common case (no masks, all frames at position
+// (0,0) with one shape, unit step, separable window): three kernels per row chunk.
+//
+// The reference evaluates the windowed cost lazily, ~18 times per pixel, each time as an
+// explicit (2Nw+1)^2 x K sum (Model.cpp:709-774).  Results parity does not need that
+// operation order, and the structure of the cost allows far less arithmetic:
+//
+//   * the window is an outer product h (x) h of 1-D Hamming vectors (model.pyx:692), so every
+//     windowed sum W[.] is a separable filter;
+//   * in the terms of Model.cpp:763-772 only  t5(p,u) = sum_k W[s_k r_k(.+u)](p)  couples the
+//     pixel p and the shift u spatially;  t1 and W[s_k] depend on the sample-window position
+//     only, t3, t2, t6 and the per-frame windowed reference mean on the reference-window
+//     position only, and  t4(p,u) = sum_k mean_k(x_ref) W[s_k](x_sam)  is a K-term dot product.
+//
+//   prep_maps   : per frame separable window sums -> maps SamSq (t1), RefSq (t3), RefM2 (t2),
+//                 RefM6 (t6) and per-frame WS_k = W[s_k], MR_k = W[r_k]/sum(w).       HBM-bound.
+//   corr_volume : the exhaustive table t5[u][p] for all (2 max_shift - 1)^2 integer shifts of a
+//                 row chunk: product planes accumulated over frames in registers, then the two
+//                 1-D filters through LDS.  K + 2(2Nw+1) FMAs per (p,u) before halo overhead.
+//                 This is the dominant kernel (fp64 FMA / LDS bound).
+//   replay_walk : one lane per pixel replays the reference's walk (umpa_walk.h) with every
+//                 cost evaluation replaced by a table lookup + the closed-form solve of
+//                 Model.cpp:849-858, so err / Ncalls / integer minimum stay bit-identical.
+//
+// LDS tiles are stored transposed ([column][row], row stride odd) so that lanes that walk
+// along rows read and write consecutive 8-byte words (no bank conflicts for ds_read_b64).
 #pragma once
 #include "umpa_direct.h"
+
 namespace umpa {
-struct TiledState {};
-struct TiledTimers { int n = 0; int name[8]; hipEvent_t t0[8], t1[8]; };
-inline bool tiled_supported(int, int, int) { return false; }
-inline int tiled_match(TiledState&, const ModelDev&, int, int, int, const RegionArgs&, hipStream_t, TiledTimers*) { return -1; }
-inline void tiled_release(TiledState&) {}
+
+#define UMPA_TILE 32
+#define UMPA_MAX_NW 8
+#define UMPA_CORR_THREADS 512
+#define UMPA_LDS_BUDGET (160 * 1024)
+
+struct Sep1D {                       // the two 1-D factors of the window, win[a][b] = hr[a]*hc[b]
+    double hr[2 * UMPA_MAX_NW + 1];
+    double hc[2 * UMPA_MAX_NW + 1];
+};
+
+struct Maps {                        // prep_maps outputs, each a full H x W plane (borders unused)
+    double* SamSq;                   // sum_k W[s_k^2]                      -> t1
+    double* RefSq;                   // sum_k W[r_k^2]                      -> t3
+    double* RefM2;                   // sum_k mean_k^2                      -> t2   (DF)
+    double* RefM6;                   // sum_k mean_k W[r_k]                 -> t6   (DF)
+    double* WS;                      // [K] planes W[s_k]                           (DF)
+    double* MR;                      // [K] planes mean_k = W[r_k]/sum(w)           (DF)
+    int H, W;
+};
+
+// Reads in[t*stride], t < CB + 2NW, and returns the CB filtered values out[o] = sum_tap h[tap] in[o+tap].
+template <int NW, int CB>
+__device__ __forceinline__ void fir_block(const double* __restrict__ in, int stride, const double* h, double* out)
+{
+    constexpr int S = 2 * NW + 1;
+#pragma unroll
+    for (int o = 0; o < CB; o++) out[o] = 0.0;
+#pragma unroll
+    for (int t = 0; t < CB + S - 1; t++) {
+        const double v = in[t * stride];
+#pragma unroll
+        for (int o = 0; o < CB; o++) {
+            const int tap = t - o;
+            if (tap >= 0 && tap < S) out[o] = fma(h[tap], v, out[o]);
+        }
+    }
 }
+
+// ------------------------------------------------------------------------------------------------
+// prep_maps
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+struct PrepCfg {
+    static constexpr int T = UMPA_TILE, S = 2 * NW + 1, Q = T + 2 * NW, QP = Q | 1, NT = 256, CB = 8;
+    static constexpr int RAW = Q * QP;                    // one transposed raw patch [c][r]
+    static constexpr int HPL = T * QP;                    // one H-filtered plane [c < T][r < Q]
+    static constexpr size_t LDS = (size_t)(2 * RAW + 4 * HPL) * sizeof(double);
+};
+
+template <int KIND, int NW>
+__global__ void __launch_bounds__(256)
+prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
+{
+    using C = PrepCfg<NW>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* rawS = reinterpret_cast<double*>(smem_raw);
+    double* rawR = rawS + C::RAW;
+    double* hpl = rawR + C::RAW;                           // 4 planes: Hs, Hss, Hr, Hrr
+
+    const int lin = xcd_band_remap(blockIdx.x, ntx * nty);
+    if (lin >= ntx * nty) return;
+    const int tx = lin % ntx, ty = lin / ntx;
+    // outputs live on x in [NW, H-NW) x [NW, W-NW); this tile's first output pixel:
+    const int r0 = NW + ty * C::T, c0 = NW + tx * C::T;
+    const int tid = threadIdx.x;
+    const size_t plane = (size_t)M.H * M.W;
+
+    // V-stage ownership: item = (ptype, rb, c), c fastest.  ptype 0: Hs, 1: Hss, 2: Hr, 3: Hrr.
+    // 4 ptypes x 4 row blocks x 32 columns = 512 items, two per thread (wave-uniform ptype).
+    double acc[2][C::CB], acc2[2][C::CB];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int o = 0; o < C::CB; o++) { acc[q][o] = 0.0; acc2[q][o] = 0.0; }
+
+    for (int k = 0; k < m.Na; k++) {
+        const FrameDesc f = m.frames[k];
+        __syncthreads();
+        // stage the raw patches, transposed; global reads coalesced along columns
+        for (int it = tid; it < C::Q * C::Q; it += C::NT) {
+            const int c = it % C::Q, r = it / C::Q;
+            const int gr = min(r0 - NW + r, f.H - 1), gc = min(c0 - NW + c, f.W - 1);
+            const size_t g = (size_t)gr * f.W + gc;
+            rawS[c * C::QP + r] = f.sam[g];
+            rawR[c * C::QP + r] = f.ref[g];
+        }
+        __syncthreads();
+        // H stage (along columns): items (which, cb, r), r fastest: 2 x 4 x Q
+        for (int it = tid; it < 2 * 4 * C::Q; it += C::NT) {
+            const int r = it % C::Q, rest = it / C::Q, cb = rest & 3, which = rest >> 2;
+            const double* src = (which ? rawR : rawS) + (cb * C::CB) * C::QP + r;
+            double lin_[C::CB], sq_[C::CB];
+#pragma unroll
+            for (int o = 0; o < C::CB; o++) { lin_[o] = 0.0; sq_[o] = 0.0; }
+#pragma unroll
+            for (int t = 0; t < C::CB + C::S - 1; t++) {
+                const double v = src[t * C::QP];
+                const double v2 = v * v;
+#pragma unroll
+                for (int o = 0; o < C::CB; o++) {
+                    const int tap = t - o;
+                    if (tap >= 0 && tap < C::S) { lin_[o] = fma(sep.hc[tap], v, lin_[o]); sq_[o] = fma(sep.hc[tap], v2, sq_[o]); }
+                }
+            }
+            double* dl = hpl + (which ? 2 : 0) * C::HPL + (cb * C::CB) * C::QP + r;
+            double* dq = dl + C::HPL;
+#pragma unroll
+            for (int o = 0; o < C::CB; o++) { dl[o * C::QP] = lin_[o]; dq[o * C::QP] = sq_[o]; }
+        }
+        __syncthreads();
+        // V stage (along rows)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int it = tid + q * C::NT;
+            const int c = it & 31, rb = (it >> 5) & 3, ptype = it >> 7;
+            if (KIND == 0 && (ptype == 0 || ptype == 2)) continue;       // NoDF needs only the squares
+            double out[C::CB];
+            fir_block<NW, C::CB>(hpl + ptype * C::HPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
+            const int gc = c0 + c;
+#pragma unroll
+            for (int o = 0; o < C::CB; o++) {
+                const int gr = r0 + rb * C::CB + o;
+                const bool inside = gr < M.H - NW && gc < M.W - NW;
+                if (ptype == 0) { if (inside) M.WS[k * plane + (size_t)gr * M.W + gc] = out[o]; }
+                else if (ptype == 2) {
+                    const double mean = out[o] / m.win_sum;                // Model.cpp:739
+                    if (inside) M.MR[k * plane + (size_t)gr * M.W + gc] = mean;
+                    acc[q][o] += mean * mean;                             // t2, Model.cpp:770
+                    acc2[q][o] += mean * out[o];                          // t6, Model.cpp:772
+                } else acc[q][o] += out[o];                               // t1 / t3
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int it = tid + q * C::NT;
+        const int c = it & 31, rb = (it >> 5) & 3, ptype = it >> 7;
+        const int gc = c0 + c;
+#pragma unroll
+        for (int o = 0; o < C::CB; o++) {
+            const int gr = r0 + rb * C::CB + o;
+            if (gr >= M.H - NW || gc >= M.W - NW) continue;
+            const size_t g = (size_t)gr * M.W + gc;
+            if (ptype == 1) M.SamSq[g] = acc[q][o];
+            else if (ptype == 3) M.RefSq[g] = acc[q][o];
+            else if (ptype == 2 && KIND == 1) { M.RefM2[g] = acc[q][o]; M.RefM6[g] = acc2[q][o]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// corr_volume
+// ------------------------------------------------------------------------------------------------
+template <int NW, int UB>
+struct CorrCfg {
+    static constexpr int T = UMPA_TILE, S = 2 * NW + 1, NT = UMPA_CORR_THREADS;
+    static constexpr int Q = T + 2 * NW;                  // q-region edge (tile + window halo)
+    static constexpr int QP = Q | 1;                      // odd row stride of the transposed tiles
+    static constexpr int NQB = NT / Q;                    // q column-blocks handled side by side
+    static constexpr int QB = (Q + NQB - 1) / NQB;        // q columns per thread
+    static constexpr int AC = NQB * QB;                   // allocated A columns (>= Q)
+    static constexpr int BC = AC + UB - 1;                // allocated B columns
+    static constexpr int BW = Q + UB - 1;                 // B columns actually staged
+    static constexpr int AFR = AC * QP, BFR = BC * QP;    // doubles per staged frame
+    static constexpr int FRAME = AFR + BFR;
+    static constexpr int PPL = Q * QP;                    // one product plane
+    static constexpr int FCH = (UMPA_LDS_BUDGET / 8) / FRAME;           // frames staged per barrier
+    static constexpr int LDS_DOUBLES = (FCH * FRAME > UB * PPL) ? FCH * FRAME : UB * PPL;
+    static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
+    static constexpr int CB = 8;                          // outputs per filter item
+    static constexpr int HITEMS = UB * (T / CB) * Q, HROUNDS = (HITEMS + NT - 1) / NT;
+    static constexpr int VITEMS = UB * (T / CB) * T, VROUNDS = (VITEMS + NT - 1) / NT;
+    static constexpr bool OK = FCH >= 1 && UB * PPL * 8 <= UMPA_LDS_BUDGET;   // frames and product planes fit into LDS
+};
+
+struct CorrArgs {
+    double* table;            // [(2ms-1)^2][rows][N1]
+    size_t slot_stride;       // rows * N1
+    int org0, org1;           // frame coordinates of output pixel (0,0) of the REGION
+    int row0, rows;           // this launch covers region rows [row0, row0+rows)
+    int N1;
+    int sigma;                // +1: B = ref sits at p+u ('sam' mode); -1: B = sam sits at p-u ('ref' mode)
+    int ntx, nty;
+};
+
+template <int NW, int UB>
+__global__ void __launch_bounds__(UMPA_CORR_THREADS)
+corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
+{
+    using C = CorrCfg<NW, UB>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+
+    const int lin = xcd_band_remap(blockIdx.x, A.ntx * A.nty);
+    if (lin >= A.ntx * A.nty) return;
+    const int tx = lin % A.ntx, ty = lin / A.ntx;
+    const int tid = threadIdx.x;
+    const int prow0 = A.row0 + ty * C::T, pcol0 = tx * C::T;       // first output pixel of the tile (region coords)
+    const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of q-region origin
+    const int ms = m.ms, UJ = 2 * ms - 1;
+    const int H = m.frames[0].H, W = m.frames[0].W;
+
+    // product-stage ownership: (qb, r), r fastest
+    const int pr = tid % C::Q, pqb = tid / C::Q;
+    const bool pactive = pqb < C::NQB;
+
+    for (int oi = -(ms - 1); oi <= ms - 1; oi++) {
+        for (int oj0 = -(ms - 1); oj0 <= ms - 1; oj0 += UB) {
+            const int nu = min(UB, ms - oj0);                         // offsets oj0 .. oj0+nu-1
+            double acc[C::QB][UB];
+#pragma unroll
+            for (int t = 0; t < C::QB; t++)
+#pragma unroll
+                for (int u = 0; u < UB; u++) acc[t][u] = 0.0;
+
+            for (int k0 = 0; k0 < m.Na; k0 += C::FCH) {
+                const int nf = min(C::FCH, m.Na - k0);
+                __syncthreads();                                      // previous users of the LDS region are done
+                for (int f = 0; f < nf; f++) {
+                    const FrameDesc fd = m.frames[k0 + f];
+                    const double* __restrict__ gA = A.sigma > 0 ? fd.sam : fd.ref;
+                    const double* __restrict__ gB = A.sigma > 0 ? fd.ref : fd.sam;
+                    double* la = lds + f * C::FRAME;
+                    double* lb = la + C::AFR;
+                    for (int it = tid; it < C::Q * C::Q; it += C::NT) {
+                        const int c = it % C::Q, r = it / C::Q;
+                        const int gr = min(max(fr0 + r, 0), H - 1), gc = min(max(fc0 + c, 0), W - 1);
+                        la[c * C::QP + r] = gA[(size_t)gr * W + gc];
+                    }
+                    for (int it = tid; it < C::Q * C::BW; it += C::NT) {
+                        const int c = it % C::BW, r = it / C::BW;
+                        const int gr = min(max(fr0 + r + oi, 0), H - 1), gc = min(max(fc0 + c + oj0, 0), W - 1);
+                        lb[c * C::QP + r] = gB[(size_t)gr * W + gc];
+                    }
+                }
+                __syncthreads();
+                if (pactive) {
+                    for (int f = 0; f < nf; f++) {
+                        const double* la = lds + f * C::FRAME + (pqb * C::QB) * C::QP + pr;
+                        const double* lb = la + C::AFR;
+                        double a[C::QB], b[C::QB + UB - 1];
+#pragma unroll
+                        for (int t = 0; t < C::QB; t++) a[t] = la[t * C::QP];
+#pragma unroll
+                        for (int t = 0; t < C::QB + UB - 1; t++) b[t] = lb[t * C::QP];
+#pragma unroll
+                        for (int t = 0; t < C::QB; t++)
+#pragma unroll
+                            for (int u = 0; u < UB; u++) acc[t][u] = fma(a[t], b[t + u], acc[t][u]);
+                    }
+                }
+            }
+            __syncthreads();                                          // frames consumed: the region becomes product planes
+            if (pactive) {
+#pragma unroll
+                for (int t = 0; t < C::QB; t++) {
+                    const int c = pqb * C::QB + t;
+                    if (c < C::Q) {
+#pragma unroll
+                        for (int u = 0; u < UB; u++) lds[u * C::PPL + c * C::QP + pr] = acc[t][u];
+                    }
+                }
+            }
+            __syncthreads();
+            // H stage (along columns), results kept in registers, then written in place
+            double hres[C::HROUNDS][C::CB];
+#pragma unroll
+            for (int rd = 0; rd < C::HROUNDS; rd++) {
+                const int it = tid + rd * C::NT;
+                if (it < C::HITEMS) {
+                    const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                    fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rd = 0; rd < C::HROUNDS; rd++) {
+                const int it = tid + rd * C::NT;
+                if (it < C::HITEMS) {
+                    const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                    double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
+#pragma unroll
+                    for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
+                }
+            }
+            __syncthreads();
+            // V stage (along rows) and store: items (u, rb, c), c fastest -> coalesced table rows
+#pragma unroll
+            for (int rd = 0; rd < C::VROUNDS; rd++) {
+                const int it = tid + rd * C::NT;
+                if (it < C::VITEMS) {
+                    const int c = it % C::T, rest = it / C::T, rb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                    if (u < nu) {
+                        double out[C::CB];
+                        fir_block<NW, C::CB>(lds + u * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
+                        const int ui = A.sigma * oi, uj = A.sigma * (oj0 + u);
+                        const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
+                        const int col = pcol0 + c;
+#pragma unroll
+                        for (int o = 0; o < C::CB; o++) {
+                            const int row = prow0 + rb * C::CB + o;               // region row
+                            if (row < A.row0 + A.rows && col < A.N1)
+                                A.table[slot * A.slot_stride + (size_t)(row - A.row0) * A.N1 + col] = out[o];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// replay_walk
+// ------------------------------------------------------------------------------------------------
+struct ReplayArgs {
+    const double* table;
+    size_t slot_stride;
+    int row0, rows;           // region rows covered by the table
+};
+
+template <int KIND>
+__device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, const ReplayArgs& R, int ref_mode,
+                                           int i, int j, size_t tpx, int si, int sj, double& cost, Fit& fit)
+{
+    const int ms = m.ms;
+    if (si <= -ms || si >= ms) return UMPA_ST_BOUND;
+    if (sj <= -ms) return UMPA_ST_BOUND | UMPA_ST_DIM;
+    if (sj >= ms) return UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
+    const int UJ = 2 * ms - 1;
+    const size_t slot = (size_t)(si + ms - 1) * UJ + (sj + ms - 1);
+    const double t5 = R.table[slot * R.slot_stride + tpx];
+    // window positions (Model.cpp:688-701)
+    const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
+    const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
+    const double t1 = M.SamSq[xs], t3 = M.RefSq[xr];
+    const double wt = (double)m.Na;
+    if (KIND == 1) {
+        const double t2 = M.RefM2[xr], t6 = M.RefM6[xr];
+        const size_t plane = (size_t)M.H * M.W;
+        double t4 = 0.0;
+        for (int k = 0; k < m.Na; k++) t4 += M.MR[k * plane + xr] * M.WS[k * plane + xs];
+        const double det = t2 * t3 - t6 * t6;                       // Model.cpp:849-858
+        const double K = (t2 * t5 - t4 * t6) / det;
+        const double beta = (t3 * t4 - t5 * t6) / det;
+        fit.t = beta + K;
+        fit.v = K / fit.t;
+        cost = (t1 + beta * beta * t2 + K * K * t3 - 2 * beta * t4 - 2 * K * t5 + 2 * beta * K * t6) / wt;
+    } else {
+        fit.t = t5 / t3;                                            // Model.cpp:502-505
+        fit.v = 0.0;
+        cost = (t1 - t5 * fit.t) / wt;
+    }
+    return UMPA_ST_OK;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 4)
+replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
+{
+    const int xj = blockIdx.x * 64 + threadIdx.x;
+    const int xi = R.row0 + blockIdx.y * 4 + threadIdx.y;
+    if (xi >= R.row0 + R.rows || xj >= A.N1) return;
+    const size_t px = (size_t)xi * A.N1 + xj;
+    const size_t tpx = (size_t)(xi - R.row0) * A.N1 + xj;
+    if (A.cover && A.cover[px] < A.thr) return;
+    const int i = A.org0 + xi, j = A.org1 + xj;
+    double memo[25], nb[16];
+    for (int q = 0; q < 16; q++) nb[q] = 0.0;
+    Walk w;
+    walk_begin(w, memo, A.uv ? A.uv[2 * px] : 0.0, A.uv ? A.uv[2 * px + 1] : 0.0);
+    while (w.phase != PH_DONE) {
+        double c = 0.0;
+        Fit fit = w.live;
+        const int st = eval_lookup<KIND>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, c, fit);
+        walk_feed(w, memo, nb, st, c, fit, m.subpx);
+    }
+    store_pixel(A, px, KIND, w, memo, nb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct TiledState {
+    double* maps = nullptr;   size_t maps_cap = 0;
+    double* table = nullptr;  size_t table_cap = 0;
+    Sep1D sep;
+    bool separable = false;
+    int sep_nw = -1;
+};
+
+struct TiledTimers { int n = 0; int name[64]; hipEvent_t t0[64], t1[64]; };
+
+inline bool tiled_supported(int Nw, int ms, int Na)
+{
+    return Nw >= 1 && Nw <= UMPA_MAX_NW && ms >= 1 && Na >= 1;
+}
+
+// factor win[a][b] = hr[a]*hc[b]; false if the window is not an outer product
+inline bool tiled_factor_window(TiledState& st, const double* win, int Nw)
+{
+    const int S = 2 * Nw + 1;
+    st.separable = false;
+    st.sep_nw = Nw;
+    if (Nw > UMPA_MAX_NW) return false;
+    const double pivot = win[Nw * S + Nw];
+    if (!(pivot > 0.0)) return false;
+    double mx = 0.0;
+    for (int a = 0; a < S; a++) { st.sep.hr[a] = win[a * S + Nw] / pivot; st.sep.hc[a] = win[Nw * S + a]; }
+    for (int n = 0; n < S * S; n++) mx = fmax(mx, fabs(win[n]));
+    for (int a = 0; a < S; a++)
+        for (int b = 0; b < S; b++)
+            if (fabs(st.sep.hr[a] * st.sep.hc[b] - win[a * S + b]) > 4e-16 * mx) return false;
+    st.separable = true;
+    return true;
+}
+
+inline void tiled_release(TiledState& st)
+{
+    if (st.maps) (void)hipFree(st.maps);
+    if (st.table) (void)hipFree(st.table);
+    st.maps = st.table = nullptr;
+    st.maps_cap = st.table_cap = 0;
+}
+
+inline int pick_ub(int UJ)
+{
+    // batch width over the column shifts: least padding, then the widest
+    int best = 5, waste = 1 << 30;
+    const int cand[3] = {9, 7, 5};
+    for (int q = 0; q < 3; q++) {
+        const int ub = cand[q], w = ((UJ + ub - 1) / ub) * ub - UJ;
+        if (w < waste) { waste = w; best = ub; }
+    }
+    return best;
+}
+
+template <int NW, int UB>
+inline hipError_t launch_corr(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
+{
+    using C = CorrCfg<NW, UB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int total = A.ntx * A.nty, grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL((corr_volume_kernel<NW, UB>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
+    return hipGetLastError();
+}
+
+template <int NW>
+inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
+{
+    if (ub == 9) {
+        if constexpr (CorrCfg<NW, 9>::OK) return launch_corr<NW, 9>(dev, A, sep, s);
+        ub = 7;
+    }
+    if (ub == 7) {
+        if constexpr (CorrCfg<NW, 7>::OK) return launch_corr<NW, 7>(dev, A, sep, s);
+        ub = 5;
+    }
+    static_assert(CorrCfg<NW, 5>::OK, "UB=5 must always fit");
+    return launch_corr<NW, 5>(dev, A, sep, s);
+}
+
+template <int KIND, int NW>
+inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& sep, hipStream_t s)
+{
+    using C = PrepCfg<NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_maps_kernel<KIND, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntx = (M.W - 2 * NW + C::T - 1) / C::T, nty = (M.H - 2 * NW + C::T - 1) / C::T;
+    const int total = ntx * nty, grid = ((total + 7) / 8) * 8;
+    hipLaunchKernelGGL((prep_maps_kernel<KIND, NW>), dim3(grid), dim3(C::NT), C::LDS, s, dev, M, sep, ntx, nty);
+    return hipGetLastError();
+}
+
+
+// ---- dispatch over the compile-time window half-width
+#define UMPA_NW_SWITCH(nw, CALL)                \
+    switch (nw) {                               \
+    case 1: { constexpr int NWC = 1; CALL; } break; \
+    case 2: { constexpr int NWC = 2; CALL; } break; \
+    case 3: { constexpr int NWC = 3; CALL; } break; \
+    case 4: { constexpr int NWC = 4; CALL; } break; \
+    case 5: { constexpr int NWC = 5; CALL; } break; \
+    case 6: { constexpr int NWC = 6; CALL; } break; \
+    case 7: { constexpr int NWC = 7; CALL; } break; \
+    case 8: { constexpr int NWC = 8; CALL; } break; \
+    default: break;                             \
+    }
+
+inline size_t tiled_table_budget()
+{
+    const char* e = getenv("UMPA_HIP_TABLE_MB");
+    long mb = e ? atol(e) : 1024;
+    if (mb < 16) mb = 16;
+    return (size_t)mb << 20;
+}
+
+// One match of a region on the tiled path.  Returns 0, -3 (allocation) or a positive hipError_t.
+inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const RegionArgs& A,
+                       hipStream_t s, TiledTimers* tt)
+{
+    const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1;
+    const size_t plane = (size_t)H * W;
+    const size_t nmaps = kind == 1 ? 4 + 2 * (size_t)K : 2;
+    if (st.maps_cap < nmaps * plane) {
+        if (st.maps) (void)hipFree(st.maps);
+        st.maps = nullptr; st.maps_cap = 0;
+        if (hipMalloc((void**)&st.maps, nmaps * plane * sizeof(double)) != hipSuccess) return -3;
+        st.maps_cap = nmaps * plane;
+    }
+    Maps M;
+    M.H = H; M.W = W;
+    M.SamSq = st.maps; M.RefSq = st.maps + plane;
+    M.RefM2 = kind == 1 ? st.maps + 2 * plane : nullptr;
+    M.RefM6 = kind == 1 ? st.maps + 3 * plane : nullptr;
+    M.WS = kind == 1 ? st.maps + 4 * plane : nullptr;
+    M.MR = kind == 1 ? st.maps + (4 + (size_t)K) * plane : nullptr;
+
+    // rows per chunk: the shift table of one chunk stays within the budget (whole tiles)
+    const size_t row_bytes = (size_t)UJ * UJ * A.N1 * sizeof(double);
+    long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
+    if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
+    if (rows_chunk > A.N0) rows_chunk = ((long)A.N0 + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+    const size_t table_need = (size_t)UJ * UJ * rows_chunk * A.N1;
+    if (st.table_cap < table_need) {
+        if (st.table) (void)hipFree(st.table);
+        st.table = nullptr; st.table_cap = 0;
+        if (hipMalloc((void**)&st.table, table_need * sizeof(double)) != hipSuccess) return -3;
+        st.table_cap = table_need;
+    }
+
+    auto tic = [&](int name) { if (tt && tt->n < 64) { tt->name[tt->n] = name; (void)hipEventCreate(&tt->t0[tt->n]); (void)hipEventCreate(&tt->t1[tt->n]); (void)hipEventRecord(tt->t0[tt->n], s); } };
+    auto toc = [&]() { if (tt && tt->n < 64) { (void)hipEventRecord(tt->t1[tt->n], s); tt->n++; } };
+
+    hipError_t e = hipErrorInvalidValue;
+    tic(2);
+    if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, s))) }
+    else { UMPA_NW_SWITCH(Nw, (e = launch_prep<0, NWC>(dev, M, st.sep, s))) }
+    toc();
+    if (e != hipSuccess) return (int)e;
+
+    const int ub = pick_ub(UJ);
+    for (int row0 = 0; row0 < A.N0; row0 += (int)rows_chunk) {
+        const int rows = (int)((A.N0 - row0 < rows_chunk) ? A.N0 - row0 : rows_chunk);
+        CorrArgs CA;
+        CA.table = st.table; CA.slot_stride = (size_t)rows * A.N1;
+        CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = row0; CA.rows = rows; CA.N1 = A.N1;
+        CA.sigma = dev.ref_mode ? -1 : 1;
+        CA.ntx = (A.N1 + UMPA_TILE - 1) / UMPA_TILE; CA.nty = (rows + UMPA_TILE - 1) / UMPA_TILE;
+        e = hipErrorInvalidValue;
+        tic(3);
+        UMPA_NW_SWITCH(Nw, (e = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s)))
+        toc();
+        if (e != hipSuccess) return (int)e;
+
+        ReplayArgs R;
+        R.table = st.table; R.slot_stride = CA.slot_stride; R.row0 = row0; R.rows = rows;
+        dim3 blk(64, 4), grd((A.N1 + 63) / 64, (rows + 3) / 4);
+        tic(4);
+        if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1>), grd, blk, 0, s, dev, M, R, A);
+        else hipLaunchKernelGGL((replay_walk_kernel<0>), grd, blk, 0, s, dev, M, R, A);
+        toc();
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+} // namespace umpa
