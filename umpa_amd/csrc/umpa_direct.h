@@ -40,6 +40,17 @@ struct RegionArgs {
     double* dbg_d; double* dbg_a; int* dbg_n;
 };
 
+// descriptor k, read through the global address space (member-wise: a struct copy across address
+// spaces does not compile in the host pass)
+__device__ __forceinline__ FrameDesc load_frame(const FrameDesc* frames, int k)
+{
+    const UMPA_GLOBAL FrameDesc* g = gp(frames) + k;
+    FrameDesc f;
+    f.sam = g->sam; f.ref = g->ref; f.mask = g->mask;
+    f.H = g->H; f.W = g->W; f.pi = g->pi; f.pj = g->pj;
+    return f;
+}
+
 __device__ __forceinline__ double pair_weight(double a, double b)   // Utils.cpp:125-130
 {
     return a * b / (a + b + 1e-8);
@@ -64,19 +75,19 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
     double wt = MASK ? 0.0 : (double)m.Na;               // Model.cpp:425,:711 / :463,:777
 
     for (int k = 0; k < m.Na; k++) {
-        const FrameDesc f = m.frames[k];
+        const FrameDesc f = load_frame(m.frames, k);
         const int li = i - f.pi, lj = j - f.pj;          // Model.cpp:430-433 / :716-719
         if (li - pad < 0 || li + pad > f.H || lj - pad < 0 || lj + pad > f.W) continue;
         const size_t ro = (size_t)(ri - f.pi - Nw) * f.W + (rj - f.pj - Nw);
         const size_t qo = (size_t)(qi - f.pi - Nw) * f.W + (qj - f.pj - Nw);
-        const double* __restrict__ R = f.ref + ro;
-        const double* __restrict__ Q = f.sam + qo;
-        const double* __restrict__ MR = MASK ? f.mask + ro : nullptr;
-        const double* __restrict__ MQ = MASK ? f.mask + qo : nullptr;
+        const UMPA_GLOBAL double* __restrict__ R = gp(f.ref) + ro;
+        const UMPA_GLOBAL double* __restrict__ Q = gp(f.sam) + qo;
+        const UMPA_GLOBAL double* __restrict__ MR = MASK ? gp(f.mask) + ro : nullptr;
+        const UMPA_GLOBAL double* __restrict__ MQ = MASK ? gp(f.mask) + qo : nullptr;
 
         double s2 = 0, s4 = 0, s6 = 0, sm = 0;
         for (int a = 0; a < S; a++) {
-            const double* wrow = m.win + a * S;
+            const UMPA_GLOBAL double* wrow = gp(m.win) + a * S;
             const size_t off = (size_t)a * f.W;
             for (int b = 0; b < S; b++) {
                 double w = wrow[b];
@@ -120,20 +131,21 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
 
 // Store one pixel's results the way Model*::min + the Cython loop do
 // (Model.cpp:573-577 / :934-938; model.pyx:487-491).
+template <class Memo>
 __device__ __forceinline__ void store_pixel(const RegionArgs& A, size_t px, int kind, const Walk& w,
-                                            const double* memo, const double* nb)
+                                            Memo memo, const double* nb)
 {
-    double* v = A.values + px * A.nparam;
+    UMPA_GLOBAL double* v = gpw(A.values) + px * A.nparam;
     v[0] = w.out;
     v[1] = w.live.t;
     v[2] = w.uv1;
     v[3] = w.uv0;
     if (kind == 1) v[4] = w.live.v;
-    if (A.uv) { A.uv[2 * px] = w.uv0; A.uv[2 * px + 1] = w.uv1; }
-    A.err[px] = w.status & UMPA_ST_OK;
-    if (A.dbg_n) A.dbg_n[px] = w.n;
-    if (A.dbg_d) for (int q = 0; q < 25; q++) A.dbg_d[px * 25 + q] = memo[q];
-    if (A.dbg_a) for (int q = 0; q < 16; q++) A.dbg_a[px * 16 + q] = nb[q];
+    if (A.uv) { gpw(A.uv)[2 * px] = w.uv0; gpw(A.uv)[2 * px + 1] = w.uv1; }
+    gpw(A.err)[px] = w.status & UMPA_ST_OK;
+    if (A.dbg_n) gpw(A.dbg_n)[px] = w.n;
+    if (A.dbg_d) for (int q = 0; q < 25; q++) gpw(A.dbg_d)[px * 25 + q] = memo[q];
+    if (A.dbg_a) for (int q = 0; q < 16; q++) gpw(A.dbg_a)[px * 16 + q] = nb[q];
 }
 
 // blockIdx -> tile remap so that each XCD (blocks b, b+8, ... share one) works on a
@@ -147,10 +159,13 @@ __device__ __forceinline__ int xcd_band_remap(int lin, int total)
 #define UMPA_DIRECT_BX 64
 #define UMPA_DIRECT_BY 4
 
+#define UMPA_WALK_THREADS (UMPA_DIRECT_BX * UMPA_DIRECT_BY)
+
 template <int KIND, bool MASK>
-__global__ void __launch_bounds__(UMPA_DIRECT_BX* UMPA_DIRECT_BY, 4)
+__global__ void __launch_bounds__(UMPA_WALK_THREADS, 3)
 match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
 {
+    __shared__ double memo_lds[25 * UMPA_WALK_THREADS];
     const int lin = xcd_band_remap(blockIdx.x, nbx * nby);
     if (lin >= nbx * nby) return;
     const int bx = lin % nbx, by = lin / nbx;
@@ -158,19 +173,20 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
     const int xi = by * UMPA_DIRECT_BY + threadIdx.y;
     if (xi >= A.N0 || xj >= A.N1) return;
     const size_t px = (size_t)xi * A.N1 + xj;
-    if (A.cover && A.cover[px] < A.thr) return;          // model.pyx:480-481: skipped pixels keep their zeros
+    if (A.cover && gp(A.cover)[px] < A.thr) return;      // model.pyx:480-481: skipped pixels keep their zeros
 
     const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
-    double memo[25], nb[16];
-    for (int q = 0; q < 16; q++) nb[q] = 0.0;
+    const LdsMemo<UMPA_WALK_THREADS> memo = {memo_lds + threadIdx.y * UMPA_DIRECT_BX + threadIdx.x};
     Walk w;
-    walk_begin(w, memo, A.uv ? A.uv[2 * px] : 0.0, A.uv ? A.uv[2 * px + 1] : 0.0);
-    while (w.phase != PH_DONE) {
+    walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
+    while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
         const int st = eval_direct<KIND, MASK>(m, i, j, w.req_i, w.req_j, c, fit);
-        walk_feed(w, memo, nb, st, c, fit, m.subpx);
+        walk_feed(w, memo, st, c, fit);
     }
+    double nb[16];
+    walk_finish(w, memo, m.subpx, nb);
     store_pixel(A, px, KIND, w, memo, nb);
 }
 
@@ -194,12 +210,12 @@ __global__ void coverage_kernel(ModelDev m, int org0, int step0, int N0, int org
     const int i = org0 + step0 * xi, j = org1 + step1 * xj, pad = m.padding;
     double c = 0.0;
     for (int k = 0; k < m.Na; k++) {
-        const FrameDesc f = m.frames[k];
+        const FrameDesc f = load_frame(m.frames, k);
         const int li = i - f.pi, lj = j - f.pj;
         if (li - pad < 0 || li + pad > f.H || lj - pad < 0 || lj + pad > f.W) continue;
-        c += has_mask ? f.mask[(size_t)li * f.W + lj] : 1.0;
+        c += has_mask ? gp(f.mask)[(size_t)li * f.W + lj] : 1.0;
     }
-    out[(size_t)xi * N1 + xj] = c;
+    gpw(out)[(size_t)xi * N1 + xj] = c;
 }
 
 __global__ void spfit_kernel(const double* a, double* io, int quad)

@@ -105,15 +105,15 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
         for (int o = 0; o < C::CB; o++) { acc[q][o] = 0.0; acc2[q][o] = 0.0; }
 
     for (int k = 0; k < m.Na; k++) {
-        const FrameDesc f = m.frames[k];
+        const FrameDesc f = load_frame(m.frames, k);
         __syncthreads();
         // stage the raw patches, transposed; global reads coalesced along columns
         for (int it = tid; it < C::Q * C::Q; it += C::NT) {
             const int c = it % C::Q, r = it / C::Q;
             const int gr = min(r0 - NW + r, f.H - 1), gc = min(c0 - NW + c, f.W - 1);
             const size_t g = (size_t)gr * f.W + gc;
-            rawS[c * C::QP + r] = f.sam[g];
-            rawR[c * C::QP + r] = f.ref[g];
+            rawS[c * C::QP + r] = gp(f.sam)[g];
+            rawR[c * C::QP + r] = gp(f.ref)[g];
         }
         __syncthreads();
         // H stage (along columns): items (which, cb, r), r fastest: 2 x 4 x Q
@@ -152,10 +152,10 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
             for (int o = 0; o < C::CB; o++) {
                 const int gr = r0 + rb * C::CB + o;
                 const bool inside = gr < M.H - NW && gc < M.W - NW;
-                if (ptype == 0) { if (inside) M.WS[k * plane + (size_t)gr * M.W + gc] = out[o]; }
+                if (ptype == 0) { if (inside) gpw(M.WS)[k * plane + (size_t)gr * M.W + gc] = out[o]; }
                 else if (ptype == 2) {
                     const double mean = out[o] / m.win_sum;                // Model.cpp:739
-                    if (inside) M.MR[k * plane + (size_t)gr * M.W + gc] = mean;
+                    if (inside) gpw(M.MR)[k * plane + (size_t)gr * M.W + gc] = mean;
                     acc[q][o] += mean * mean;                             // t2, Model.cpp:770
                     acc2[q][o] += mean * out[o];                          // t6, Model.cpp:772
                 } else acc[q][o] += out[o];                               // t1 / t3
@@ -172,9 +172,9 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
             const int gr = r0 + rb * C::CB + o;
             if (gr >= M.H - NW || gc >= M.W - NW) continue;
             const size_t g = (size_t)gr * M.W + gc;
-            if (ptype == 1) M.SamSq[g] = acc[q][o];
-            else if (ptype == 3) M.RefSq[g] = acc[q][o];
-            else if (ptype == 2 && KIND == 1) { M.RefM2[g] = acc[q][o]; M.RefM6[g] = acc2[q][o]; }
+            if (ptype == 1) gpw(M.SamSq)[g] = acc[q][o];
+            else if (ptype == 3) gpw(M.RefSq)[g] = acc[q][o];
+            else if (ptype == 2 && KIND == 1) { gpw(M.RefM2)[g] = acc[q][o]; gpw(M.RefM6)[g] = acc2[q][o]; }
         }
     }
 }
@@ -212,6 +212,7 @@ struct CorrArgs {
     int N1;
     int sigma;                // +1: B = ref sits at p+u ('sam' mode); -1: B = sam sits at p-u ('ref' mode)
     int ntx, nty;
+    int ablate;               // diagnostics only (UMPA_HIP_ABLATE): 1 no global loads, 2 no LDS staging writes, 4 no products, 8 no filters
 };
 
 template <int NW, int UB>
@@ -222,117 +223,169 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
 
-    const int lin = xcd_band_remap(blockIdx.x, A.ntx * A.nty);
-    if (lin >= A.ntx * A.nty) return;
+    // One workgroup = one (tile, pass): a pass is one row offset oi and one batch of UB column offsets.
+    // The passes of a tile read the same A patch and overlapping B patches; they get consecutive slots
+    // on ONE XCD (blocks b, b+8, ... share an XCD) so that those re-reads are served by that XCD's L2
+    // instead of crossing the fabric once per pass.  Placement only affects speed.
+    const int ms = m.ms, UJ = 2 * ms - 1;
+    const int nbatch = (UJ + UB - 1) / UB, npass = UJ * nbatch;
+    const int ntiles = A.ntx * A.nty, tiles_per_xcd = (ntiles + 7) >> 3;
+    const int seq = blockIdx.x >> 3;                                  // position in this XCD's queue
+    const int lin = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;   // contiguous band of tiles per XCD
+    const int pass = seq % npass;
+    if (seq / npass >= tiles_per_xcd || lin >= ntiles) return;
     const int tx = lin % A.ntx, ty = lin / A.ntx;
     const int tid = threadIdx.x;
-    const int prow0 = A.row0 + ty * C::T, pcol0 = tx * C::T;       // first output pixel of the tile (region coords)
-    const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of q-region origin
-    const int ms = m.ms, UJ = 2 * ms - 1;
-    const int H = m.frames[0].H, W = m.frames[0].W;
+    const int prow0 = A.row0 + ty * C::T, pcol0 = tx * C::T;          // first output pixel of the tile (region coords)
+    const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
+    const int H = gp(m.frames)->H, W = gp(m.frames)->W;
+    const int oi = pass / nbatch - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
+
+    // ---- staging slots of this thread (compile-time counts, so everything below indexes registers statically)
+    constexpr int NA = (C::Q * C::Q + C::NT - 1) / C::NT;             // A elements per thread and frame
+    constexpr int NB = (C::Q * C::BW + C::NT - 1) / C::NT;            // B elements per thread and frame
+    int a_lds[NA], a_g[NA], b_lds[NB], b_r[NB], b_c[NB], b_g[NB];
+#pragma unroll
+    for (int n = 0; n < NA; n++) {
+        const int it = tid + n * C::NT, c = it % C::Q, r = it / C::Q;
+        a_lds[n] = it < C::Q * C::Q ? c * C::QP + r : -1;
+        a_g[n] = min(max(fr0 + r, 0), H - 1) * W + min(max(fc0 + c, 0), W - 1);
+    }
+#pragma unroll
+    for (int n = 0; n < NB; n++) {
+        const int it = tid + n * C::NT, c = it % C::BW, r = it / C::BW;
+        b_lds[n] = it < C::Q * C::BW ? c * C::QP + r : -1;
+        b_r[n] = fr0 + r;
+        b_c[n] = fc0 + c;
+    }
+    double pa[C::FCH][NA], pb[C::FCH][NB];                            // frames in flight from HBM/L2
+
+    const int nchunk = (m.Na + C::FCH - 1) / C::FCH;
+#pragma unroll
+    for (int n = 0; n < NB; n++)
+        b_g[n] = min(max(b_r[n] + oi, 0), H - 1) * W + min(max(b_c[n] + oj0, 0), W - 1);
+
+    auto issue_loads = [&](int chunk) {
+        const int k0 = chunk * C::FCH;
+#pragma unroll
+        for (int f = 0; f < C::FCH; f++) {
+            if (k0 + f < m.Na) {
+                const FrameDesc fd = load_frame(m.frames, k0 + f);
+                const UMPA_GLOBAL double* __restrict__ gA = gp(A.sigma > 0 ? fd.sam : fd.ref);
+                const UMPA_GLOBAL double* __restrict__ gB = gp(A.sigma > 0 ? fd.ref : fd.sam);
+                if (A.ablate & 1) {
+#pragma unroll
+                    for (int n = 0; n < NA; n++) pa[f][n] = 1.0;
+#pragma unroll
+                    for (int n = 0; n < NB; n++) pb[f][n] = 1.0;
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NA; n++) pa[f][n] = gA[a_g[n]];
+#pragma unroll
+                    for (int n = 0; n < NB; n++) pb[f][n] = gB[b_g[n]];
+                }
+            }
+        }
+    };
 
     // product-stage ownership: (qb, r), r fastest
     const int pr = tid % C::Q, pqb = tid / C::Q;
     const bool pactive = pqb < C::NQB;
+    double acc[C::QB][UB];
 
-    for (int oi = -(ms - 1); oi <= ms - 1; oi++) {
-        for (int oj0 = -(ms - 1); oj0 <= ms - 1; oj0 += UB) {
-            const int nu = min(UB, ms - oj0);                         // offsets oj0 .. oj0+nu-1
-            double acc[C::QB][UB];
 #pragma unroll
-            for (int t = 0; t < C::QB; t++)
+    for (int t = 0; t < C::QB; t++)
 #pragma unroll
-                for (int u = 0; u < UB; u++) acc[t][u] = 0.0;
-
-            for (int k0 = 0; k0 < m.Na; k0 += C::FCH) {
-                const int nf = min(C::FCH, m.Na - k0);
-                __syncthreads();                                      // previous users of the LDS region are done
-                for (int f = 0; f < nf; f++) {
-                    const FrameDesc fd = m.frames[k0 + f];
-                    const double* __restrict__ gA = A.sigma > 0 ? fd.sam : fd.ref;
-                    const double* __restrict__ gB = A.sigma > 0 ? fd.ref : fd.sam;
-                    double* la = lds + f * C::FRAME;
-                    double* lb = la + C::AFR;
-                    for (int it = tid; it < C::Q * C::Q; it += C::NT) {
-                        const int c = it % C::Q, r = it / C::Q;
-                        const int gr = min(max(fr0 + r, 0), H - 1), gc = min(max(fc0 + c, 0), W - 1);
-                        la[c * C::QP + r] = gA[(size_t)gr * W + gc];
-                    }
-                    for (int it = tid; it < C::Q * C::BW; it += C::NT) {
-                        const int c = it % C::BW, r = it / C::BW;
-                        const int gr = min(max(fr0 + r + oi, 0), H - 1), gc = min(max(fc0 + c + oj0, 0), W - 1);
-                        lb[c * C::QP + r] = gB[(size_t)gr * W + gc];
-                    }
-                }
-                __syncthreads();
-                if (pactive) {
-                    for (int f = 0; f < nf; f++) {
-                        const double* la = lds + f * C::FRAME + (pqb * C::QB) * C::QP + pr;
-                        const double* lb = la + C::AFR;
-                        double a[C::QB], b[C::QB + UB - 1];
+        for (int u = 0; u < UB; u++) acc[t][u] = 0.0;
+    issue_loads(0);
+    for (int chunk = 0; chunk < nchunk; chunk++) {
+        const int k0 = chunk * C::FCH;
+        const int nf = min(C::FCH, m.Na - k0);
+        __syncthreads();                                              // every reader of the LDS region is done
 #pragma unroll
-                        for (int t = 0; t < C::QB; t++) a[t] = la[t * C::QP];
+        for (int f = 0; f < C::FCH; f++) {
+            if (f < nf && !(A.ablate & 2)) {
+                double* la = lds + f * C::FRAME;
+                double* lb = la + C::AFR;
 #pragma unroll
-                        for (int t = 0; t < C::QB + UB - 1; t++) b[t] = lb[t * C::QP];
+                for (int n = 0; n < NA; n++) if (a_lds[n] >= 0) la[a_lds[n]] = pa[f][n];
 #pragma unroll
-                        for (int t = 0; t < C::QB; t++)
+                for (int n = 0; n < NB; n++) if (b_lds[n] >= 0) lb[b_lds[n]] = pb[f][n];
+            }
+        }
+        if (chunk + 1 < nchunk) issue_loads(chunk + 1);               // flies while this chunk is consumed
+        __syncthreads();
+        if (pactive && !(A.ablate & 4)) {
+            for (int f = 0; f < nf; f++) {
+                const double* la = lds + f * C::FRAME + (pqb * C::QB) * C::QP + pr;
+                const double* lb = la + C::AFR;
+                double a[C::QB], b[C::QB + UB - 1];
 #pragma unroll
-                            for (int u = 0; u < UB; u++) acc[t][u] = fma(a[t], b[t + u], acc[t][u]);
-                    }
+                for (int t = 0; t < C::QB; t++) a[t] = la[t * C::QP];
+#pragma unroll
+                for (int t = 0; t < C::QB + UB - 1; t++) b[t] = lb[t * C::QP];
+#pragma unroll
+                for (int t = 0; t < C::QB; t++)
+#pragma unroll
+                    for (int u = 0; u < UB; u++) acc[t][u] = fma(a[t], b[t + u], acc[t][u]);
+            }
+        }
+    }
+    if (A.ablate & 8) return;
+    {
+        // ---- all frames of this pass are in: product planes -> LDS, H filter, V filter, store
+        const int nu = min(UB, ms - oj0);                             // offsets oj0 .. oj0+nu-1 are real
+        __syncthreads();                                              // frames consumed: the region becomes product planes
+        if (pactive) {
+#pragma unroll
+            for (int t = 0; t < C::QB; t++) {
+                const int c = pqb * C::QB + t;
+                if (c < C::Q) {
+#pragma unroll
+                    for (int u = 0; u < UB; u++) lds[u * C::PPL + c * C::QP + pr] = acc[t][u];
                 }
             }
-            __syncthreads();                                          // frames consumed: the region becomes product planes
-            if (pactive) {
+        }
+        __syncthreads();
+        // H stage (along columns), results kept in registers, then written in place
+        double hres[C::HROUNDS][C::CB];
 #pragma unroll
-                for (int t = 0; t < C::QB; t++) {
-                    const int c = pqb * C::QB + t;
-                    if (c < C::Q) {
-#pragma unroll
-                        for (int u = 0; u < UB; u++) lds[u * C::PPL + c * C::QP + pr] = acc[t][u];
-                    }
-                }
+        for (int rd = 0; rd < C::HROUNDS; rd++) {
+            const int it = tid + rd * C::NT;
+            if (it < C::HITEMS) {
+                const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
             }
-            __syncthreads();
-            // H stage (along columns), results kept in registers, then written in place
-            double hres[C::HROUNDS][C::CB];
+        }
+        __syncthreads();
 #pragma unroll
-            for (int rd = 0; rd < C::HROUNDS; rd++) {
-                const int it = tid + rd * C::NT;
-                if (it < C::HITEMS) {
-                    const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
-                    fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
-                }
+        for (int rd = 0; rd < C::HROUNDS; rd++) {
+            const int it = tid + rd * C::NT;
+            if (it < C::HITEMS) {
+                const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
+#pragma unroll
+                for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        // V stage (along rows) and store: items (u, rb, c), c fastest -> coalesced table rows
 #pragma unroll
-            for (int rd = 0; rd < C::HROUNDS; rd++) {
-                const int it = tid + rd * C::NT;
-                if (it < C::HITEMS) {
-                    const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
-                    double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
+        for (int rd = 0; rd < C::VROUNDS; rd++) {
+            const int it = tid + rd * C::NT;
+            if (it < C::VITEMS) {
+                const int c = it % C::T, rest = it / C::T, rb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                if (u < nu) {
+                    double out[C::CB];
+                    fir_block<NW, C::CB>(lds + u * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
+                    const int ui = A.sigma * oi, uj = A.sigma * (oj0 + u);
+                    const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
+                    const int col = pcol0 + c;
 #pragma unroll
-                    for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
-                }
-            }
-            __syncthreads();
-            // V stage (along rows) and store: items (u, rb, c), c fastest -> coalesced table rows
-#pragma unroll
-            for (int rd = 0; rd < C::VROUNDS; rd++) {
-                const int it = tid + rd * C::NT;
-                if (it < C::VITEMS) {
-                    const int c = it % C::T, rest = it / C::T, rb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
-                    if (u < nu) {
-                        double out[C::CB];
-                        fir_block<NW, C::CB>(lds + u * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
-                        const int ui = A.sigma * oi, uj = A.sigma * (oj0 + u);
-                        const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
-                        const int col = pcol0 + c;
-#pragma unroll
-                        for (int o = 0; o < C::CB; o++) {
-                            const int row = prow0 + rb * C::CB + o;               // region row
-                            if (row < A.row0 + A.rows && col < A.N1)
-                                A.table[slot * A.slot_stride + (size_t)(row - A.row0) * A.N1 + col] = out[o];
-                        }
+                    for (int o = 0; o < C::CB; o++) {
+                        const int row = prow0 + rb * C::CB + o;               // region row
+                        if (row < A.row0 + A.rows && col < A.N1)
+                            gpw(A.table)[slot * A.slot_stride + (size_t)(row - A.row0) * A.N1 + col] = out[o];
                     }
                 }
             }
@@ -349,9 +402,15 @@ struct ReplayArgs {
     int row0, rows;           // region rows covered by the table
 };
 
+#define UMPA_KFIX 16          // frames whose fixed-window map value is kept in registers by replay_walk
+
+// One "cost evaluation" of the walk: table lookup + maps + the closed-form solve of Model.cpp:849-858.
+// `fixed[k]` holds, for k < UMPA_KFIX, the per-frame map at the window that does not move with the shift
+// (W[s_k](p) in 'sam' mode, mean_k(p) in 'ref' mode); `movmap` is the other per-frame map.
 template <int KIND>
 __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, const ReplayArgs& R, int ref_mode,
-                                           int i, int j, size_t tpx, int si, int sj, double& cost, Fit& fit)
+                                           int i, int j, size_t tpx, int si, int sj,
+                                           const double* fixed, double& cost, Fit& fit)
 {
     const int ms = m.ms;
     if (si <= -ms || si >= ms) return UMPA_ST_BOUND;
@@ -359,17 +418,26 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     if (sj >= ms) return UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
     const int UJ = 2 * ms - 1;
     const size_t slot = (size_t)(si + ms - 1) * UJ + (sj + ms - 1);
-    const double t5 = R.table[slot * R.slot_stride + tpx];
+    const double t5 = gp(R.table)[slot * R.slot_stride + tpx];
     // window positions (Model.cpp:688-701)
     const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
     const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
-    const double t1 = M.SamSq[xs], t3 = M.RefSq[xr];
+    const double t1 = gp(M.SamSq)[xs], t3 = gp(M.RefSq)[xr];
     const double wt = (double)m.Na;
     if (KIND == 1) {
-        const double t2 = M.RefM2[xr], t6 = M.RefM6[xr];
+        const double t2 = gp(M.RefM2)[xr], t6 = gp(M.RefM6)[xr];
         const size_t plane = (size_t)M.H * M.W;
+        const UMPA_GLOBAL double* __restrict__ mov = gp(ref_mode ? M.WS : M.MR) + (ref_mode ? xs : xr);
+        double mv[UMPA_KFIX];
+#pragma unroll
+        for (int k = 0; k < UMPA_KFIX; k++) mv[k] = k < m.Na ? mov[k * plane] : 0.0;    // all loads in flight together
         double t4 = 0.0;
-        for (int k = 0; k < m.Na; k++) t4 += M.MR[k * plane + xr] * M.WS[k * plane + xs];
+#pragma unroll
+        for (int k = 0; k < UMPA_KFIX; k++) if (k < m.Na) t4 += mv[k] * fixed[k];
+        if (m.Na > UMPA_KFIX) {
+            const UMPA_GLOBAL double* __restrict__ fx = gp(ref_mode ? M.MR : M.WS) + (ref_mode ? xr : xs);
+            for (int k = UMPA_KFIX; k < m.Na; k++) t4 += mov[k * plane] * fx[k * plane];
+        }
         const double det = t2 * t3 - t6 * t6;                       // Model.cpp:849-858
         const double K = (t2 * t5 - t4 * t6) / det;
         const double beta = (t3 * t4 - t5 * t6) / det;
@@ -385,26 +453,35 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(UMPA_WALK_THREADS, 3)
 replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
 {
+    __shared__ double memo_lds[25 * UMPA_WALK_THREADS];
     const int xj = blockIdx.x * 64 + threadIdx.x;
     const int xi = R.row0 + blockIdx.y * 4 + threadIdx.y;
     if (xi >= R.row0 + R.rows || xj >= A.N1) return;
     const size_t px = (size_t)xi * A.N1 + xj;
     const size_t tpx = (size_t)(xi - R.row0) * A.N1 + xj;
-    if (A.cover && A.cover[px] < A.thr) return;
+    if (A.cover && gp(A.cover)[px] < A.thr) return;
     const int i = A.org0 + xi, j = A.org1 + xj;
-    double memo[25], nb[16];
-    for (int q = 0; q < 16; q++) nb[q] = 0.0;
+    double fixed[UMPA_KFIX];
+    if (KIND == 1) {
+        const size_t plane = (size_t)M.H * M.W;
+        const UMPA_GLOBAL double* __restrict__ fx = gp(m.ref_mode ? M.MR : M.WS) + (size_t)i * M.W + j;
+#pragma unroll
+        for (int k = 0; k < UMPA_KFIX; k++) fixed[k] = k < m.Na ? fx[k * plane] : 0.0;
+    }
+    const LdsMemo<UMPA_WALK_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
     Walk w;
-    walk_begin(w, memo, A.uv ? A.uv[2 * px] : 0.0, A.uv ? A.uv[2 * px + 1] : 0.0);
-    while (w.phase != PH_DONE) {
+    walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
+    while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
-        const int st = eval_lookup<KIND>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, c, fit);
-        walk_feed(w, memo, nb, st, c, fit, m.subpx);
+        const int st = eval_lookup<KIND>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, c, fit);
+        walk_feed(w, memo, st, c, fit);
     }
+    double nb[16];
+    walk_finish(w, memo, m.subpx, nb);
     store_pixel(A, px, KIND, w, memo, nb);
 }
 
@@ -476,7 +553,9 @@ inline hipError_t launch_corr(const ModelDev& dev, const CorrArgs& A, const Sep1
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int total = A.ntx * A.nty, grid = ((total + 7) / 8) * 8;
+    const int UJ = 2 * dev.ms - 1, npass = UJ * ((UJ + UB - 1) / UB);
+    const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
+    const int grid = 8 * tiles_per_xcd * npass;
     hipLaunchKernelGGL((corr_volume_kernel<NW, UB>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
     return hipGetLastError();
 }
@@ -531,7 +610,7 @@ inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& s
 inline size_t tiled_table_budget()
 {
     const char* e = getenv("UMPA_HIP_TABLE_MB");
-    long mb = e ? atol(e) : 1024;
+    long mb = e ? atol(e) : 4096;
     if (mb < 16) mb = 16;
     return (size_t)mb << 20;
 }
@@ -587,6 +666,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         CA.table = st.table; CA.slot_stride = (size_t)rows * A.N1;
         CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = row0; CA.rows = rows; CA.N1 = A.N1;
         CA.sigma = dev.ref_mode ? -1 : 1;
+        { const char* ab = getenv("UMPA_HIP_ABLATE"); CA.ablate = ab ? atoi(ab) : 0; }
         CA.ntx = (A.N1 + UMPA_TILE - 1) / UMPA_TILE; CA.nty = (rows + UMPA_TILE - 1) / UMPA_TILE;
         e = hipErrorInvalidValue;
         tic(3);

@@ -21,9 +21,28 @@
 
 namespace umpa {
 
+// Pointers that reach a kernel inside a by-value struct, or are loaded from a descriptor table, are
+// "generic" to the compiler and turn into flat_load / flat_store, which also tick the LDS counter
+// (lgkmcnt) and so serialise against ds_read / ds_write.  Every such pointer is device memory here:
+// say so, and get global_load / global_store.
+#define UMPA_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const UMPA_GLOBAL T* gp(const T* p) { return (const UMPA_GLOBAL T*)p; }
+template <class T>
+__device__ __forceinline__ UMPA_GLOBAL T* gpw(T* p) { return (UMPA_GLOBAL T*)p; }
+
 struct Fit { double t, v; };       // the CostArgs payload (Model.h:29-52)
 
-enum Phase { PH_CENTRE = 0, PH_LO = 1, PH_HI = 2, PH_GATHER = 3, PH_DONE = 4 };
+enum Phase { PH_CENTRE = 0, PH_LO = 1, PH_HI = 2, PH_GATHER = 3, PH_FIT = 4, PH_DONE = 5 };
+
+// The 5x5 memo lives in LDS, one column per lane ([cell][lane]): the walk indexes it with
+// run-time cell numbers, which would push a per-lane array into scratch memory (HBM-backed,
+// ~10x the latency).  25 cells x 256 lanes x 8 B = 50 KiB per workgroup, conflict-free.
+template <int STRIDE>
+struct LdsMemo {
+    double* p;
+    __device__ __forceinline__ double& operator[](int q) const { return p[q * STRIDE]; }
+};
 
 struct Walk {
     int ci, cj;        // integer centre of the 5x5 memo
@@ -128,7 +147,8 @@ __device__ inline double spmin_quad(const double* a, double& px, double& py)
 
 // ---------------------------------------------------------------- the walk
 
-__device__ inline void walk_begin(Walk& w, double* memo, double u0, double u1)
+template <class Memo>
+__device__ inline void walk_begin(Walk& w, Memo memo, double u0, double u1)
 {
 #pragma unroll
     for (int q = 0; q < 25; q++) memo[q] = -1.0;               // Optim.cpp:252
@@ -151,7 +171,8 @@ __device__ inline void walk_begin(Walk& w, double* memo, double u0, double u1)
     w.uv1 = u1;
 }
 
-__device__ inline void memo_shift(double* d, int axis, int dir)
+template <class Memo>
+__device__ inline void memo_shift(Memo d, int axis, int dir)
 {
     // Optim.cpp:436-470: the centre moved by `dir` along `axis`; cells that scroll in are unknown
     if (axis) {
@@ -178,8 +199,10 @@ __device__ inline void memo_shift(double* d, int axis, int dir)
 }
 
 // Deliver the result of the pending request (status `st`, cost `val`, fit parameters `fit`)
-// and advance to the next request or to PH_DONE.
-__device__ inline void walk_feed(Walk& w, double* memo, double* nb, int st, double val, Fit fit, int subpx)
+// and advance to the next request, to PH_FIT (4x4 neighbourhood complete: walk_finish does the
+// sub-pixel fit once for the whole wave) or to PH_DONE (failed).
+template <class Memo>
+__device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit)
 {
     enum { PC_CHECK, PC_LO, PC_HI, PC_DECIDE, PC_GATHER };
     w.n++;                                                      // Ncalls counts failed calls too (Optim.cpp:263-264)
@@ -210,8 +233,7 @@ __device__ inline void walk_feed(Walk& w, double* memo, double* nb, int st, doub
         break;
     default: {                                                  // PH_GATHER, Optim.cpp:353-378
         const int r = w.g >> 2, c = w.g & 3;
-        nb[w.g] = val;
-        memo[5 * (w.ip + r) + w.jp + c] = val;
+        memo[5 * (w.ip + r) + w.jp + c] = val;                  // the `a` entry is this memo cell (Optim.cpp:357-362)
         if (val < memo[12]) {                                   // missed a lower value: hard restart
             w.ci += w.ip + r - 2;
             w.cj += w.jp + c - 2;
@@ -295,20 +317,34 @@ __device__ inline void walk_feed(Walk& w, double* memo, double* nb, int st, doub
                 w.req_j = w.cj + w.jp + c - 2;
                 return;
             }
-            nb[w.g] = known;
             w.g++;
         }
         w.live = w.kept;                                        // Optim.cpp:386
-        double x = 1.0 - w.ip, y = 1.0 - w.jp;                  // Optim.cpp:395-396
-        if (subpx == 0) w.out = x;                              // Optim.cpp:399
-        else if (subpx == 1) w.out = spmin_quad(nb, x, y);
-        else w.out = spmin(nb, x, y);
-        w.uv0 = x + (w.ci + w.ip - 1.0);                        // Optim.cpp:407-408
-        w.uv1 = y + (w.cj + w.jp - 1.0);
         w.status = st;
-        w.phase = PH_DONE;
+        w.phase = PH_FIT;
         return;
     }
+}
+
+// Sub-pixel refinement for the lanes whose walk completed (Optim.cpp:386-410).  `nb` receives the
+// 4x4 neighbourhood (minimizer_debug::a); it is the (ip,jp) sub-block of the memo.
+template <class Memo>
+__device__ inline void walk_finish(Walk& w, Memo memo, int subpx, double* nb)
+{
+    if (w.phase != PH_FIT) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) nb[g] = 0.0;
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g++) nb[g] = memo[5 * (w.ip + (g >> 2)) + w.jp + (g & 3)];
+    double x = 1.0 - w.ip, y = 1.0 - w.jp;                      // Optim.cpp:395-396
+    if (subpx == 0) w.out = x;                                  // Optim.cpp:399
+    else if (subpx == 1) w.out = spmin_quad(nb, x, y);
+    else w.out = spmin(nb, x, y);
+    w.uv0 = x + (w.ci + w.ip - 1.0);                            // Optim.cpp:407-408
+    w.uv1 = y + (w.cj + w.jp - 1.0);
+    w.phase = PH_DONE;
 }
 
 } // namespace umpa
