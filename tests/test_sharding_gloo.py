@@ -1,0 +1,94 @@
+"""
+Multi-process tests of the row-slab sharding (umpa_amd/sharding.py) on CPU: torch.distributed with the
+gloo backend, world_size 2 and 3.  The pixel work itself is done by the CPU oracle here (no GPU in
+this leg); what is tested is the partitioning, the halo arithmetic, the neighbour halo exchange and
+the gather -- the sharded result must equal the unsharded one bit for bit.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import cpu_model
+    from umpa_amd import sharding
+    from umpa_amd.synth import make_stack
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nw, ms = 2, 3
+        sam, ref, _ = make_stack(61, 70, 3, ms, df=True, seed=5, amplitude=1.5)
+        P = Nw + ms
+        n_out = sam.shape[1] - 2 * P
+
+        # (1) host-owned frames: every rank matches its slab, rank 0 gathers
+        res, (r0, r1) = sharding.match_rows(cpu_model.port.UMPAModelDF, sam, ref, Nw, ms, world, rank, num_threads=1)
+        assert res["f"].shape[0] == r1 - r0
+        whole = sharding.gather_rows({k: res[k] for k in ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls")}, n_out, dst=0)
+
+        # (2) device-sharded frames: each rank owns a disjoint block of INPUT rows and fetches the halo
+        a, b = sharding.input_rows(n_out, P, world, rank)
+        own0 = a if rank == 0 else a + P               # interior ranks own [a+P, b-P); edges own their outer halo too
+        own1 = b if rank == world - 1 else b - P
+        halo = 2 * P                                   # neighbours' slabs start P rows inside ours
+        mine = torch.from_numpy(np.ascontiguousarray(sam[:, own0:own1]))
+        padded = sharding.exchange_halo(mine, halo, None)
+        lo = own0 - (halo if rank > 0 else 0)
+        np.testing.assert_array_equal(padded.numpy(), sam[:, lo: own1 + (halo if rank < world - 1 else 0)])
+        assert lo <= a and own1 + (halo if rank < world - 1 else 0) >= b      # slab + halo is covered
+
+        # (3) all_gather variant
+        every = sharding.gather_rows({"err": res["err"]}, n_out, dst=None)
+        assert every["err"].shape[0] == n_out
+
+        if rank == 0:
+            full = cpu_model.port.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
+            for k in ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls"):
+                np.testing.assert_array_equal(whole[k], full[k], err_msg=k)
+            np.testing.assert_array_equal(every["err"], full["err"])
+            open(os.path.join(tmp, "ok_%d" % world), "w").write("ok")
+        else:
+            assert whole is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharding_matches_unsharded(world, tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import cpu_model
+    cpu_model.native("port")            # build the checker once, before forking workers
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / ("ok_%d" % world)).exists()
+
+
+def test_slab_bounds_partition():
+    from umpa_amd.sharding import input_rows, slab_bounds
+    for n in (1, 7, 8172, 2028):
+        for world in (1, 2, 3, 8):
+            edges = [slab_bounds(n, world, g) for g in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[g][1] == edges[g + 1][0] for g in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    # BASELINE config C4: 8172 output rows over 8 GPUs -> 4 x 1022 + 4 x 1021, 10 halo rows each side
+    assert [slab_bounds(8172, 8, g)[1] - slab_bounds(8172, 8, g)[0] for g in range(8)] == [1022] * 4 + [1021] * 4
+    assert input_rows(8172, 10, 8, 3) == (3 * 1022, 4 * 1022 + 20)
