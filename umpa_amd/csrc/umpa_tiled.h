@@ -50,20 +50,20 @@ struct Maps {                        // prep_maps outputs, each a full H x W pla
 };
 
 // Reads in[t*stride], t < CB + 2NW, and returns the CB filtered values out[o] = sum_tap h[tap] in[o+tap].
+// All inputs are fetched before the first FMA so the LDS latency is paid once per item, not once per read.
 template <int NW, int CB>
 __device__ __forceinline__ void fir_block(const double* __restrict__ in, int stride, const double* h, double* out)
 {
     constexpr int S = 2 * NW + 1;
+    double v[CB + S - 1];
 #pragma unroll
-    for (int o = 0; o < CB; o++) out[o] = 0.0;
+    for (int t = 0; t < CB + S - 1; t++) v[t] = in[t * stride];
 #pragma unroll
-    for (int t = 0; t < CB + S - 1; t++) {
-        const double v = in[t * stride];
+    for (int o = 0; o < CB; o++) {
+        double acc = 0.0;
 #pragma unroll
-        for (int o = 0; o < CB; o++) {
-            const int tap = t - o;
-            if (tap >= 0 && tap < S) out[o] = fma(h[tap], v, out[o]);
-        }
+        for (int tap = 0; tap < S; tap++) acc = fma(h[tap], v[o + tap], acc);
+        out[o] = acc;
     }
 }
 
@@ -423,7 +423,7 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
     const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
     const double t1 = gp(M.SamSq)[xs], t3 = gp(M.RefSq)[xr];
-    const double wt = (double)m.Na;
+    const double rwt = 1.0 / (double)m.Na;                          // wave-uniform: scalar
     if (KIND == 1) {
         const double t2 = gp(M.RefM2)[xr], t6 = gp(M.RefM6)[xr];
         const size_t plane = (size_t)M.H * M.W;
@@ -438,16 +438,19 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
             const UMPA_GLOBAL double* __restrict__ fx = gp(ref_mode ? M.MR : M.WS) + (ref_mode ? xr : xs);
             for (int k = UMPA_KFIX; k < m.Na; k++) t4 += mov[k * plane] * fx[k * plane];
         }
-        const double det = t2 * t3 - t6 * t6;                       // Model.cpp:849-858
-        const double K = (t2 * t5 - t4 * t6) / det;
-        const double beta = (t3 * t4 - t5 * t6) / det;
+        // Model.cpp:849-858 with one reciprocal instead of the reference's three divisions by the same
+        // determinant and the division by wt (1-ulp level differences; the bar is 1e-5).  The dark-field
+        // value v = K/T is only needed for the pixel's final answer: `fit.v` carries K, replay_walk divides once.
+        const double rdet = 1.0 / (t2 * t3 - t6 * t6);
+        const double K = (t2 * t5 - t4 * t6) * rdet;
+        const double beta = (t3 * t4 - t5 * t6) * rdet;
         fit.t = beta + K;
-        fit.v = K / fit.t;
-        cost = (t1 + beta * beta * t2 + K * K * t3 - 2 * beta * t4 - 2 * K * t5 + 2 * beta * K * t6) / wt;
+        fit.v = K;
+        cost = (t1 + beta * beta * t2 + K * K * t3 - 2 * beta * t4 - 2 * K * t5 + 2 * beta * K * t6) * rwt;
     } else {
         fit.t = t5 / t3;                                            // Model.cpp:502-505
         fit.v = 0.0;
-        cost = (t1 - t5 * fit.t) / wt;
+        cost = (t1 - t5 * fit.t) * rwt;
     }
     return UMPA_ST_OK;
 }
@@ -482,6 +485,8 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
     }
     double nb[16];
     walk_finish(w, memo, m.subpx, nb);
+    if (KIND == 1 && (w.live.t != 0.0 || w.live.v != 0.0))          // eval_lookup left K in the v slot; (0,0) = never evaluated
+        w.live.v = w.live.v / w.live.t;                             // Model.cpp:854
     store_pixel(A, px, KIND, w, memo, nb);
 }
 
