@@ -33,7 +33,7 @@ extern "C" {
 
 #define UMPA_HIP_KIND_NODF      0   /* models::ModelNoDF      Model.h:126-140 */
 #define UMPA_HIP_KIND_DF        1   /* models::ModelDF        Model.h:145-164 */
-#define UMPA_HIP_KIND_DFKERNEL  2   /* models::ModelDFKernel  Model.h:170-189 (not built yet: E_UNSUPPORTED) */
+#define UMPA_HIP_KIND_DFKERNEL  2   /* models::ModelDFKernel  Model.h:170-189 (direct kernel only; values[4..6] = a,b,c in) */
 
 #define UMPA_HIP_ST_OK          1
 #define UMPA_HIP_ST_BOUND       2
@@ -88,7 +88,8 @@ int umpa_hip_coverage(umpa_hip_model *m, double *out, int i, int j);
 int umpa_hip_coverage_region(umpa_hip_model *m, int start0, int step0, int N0,
                              int start1, int step1, int N1, double *out);
 
-/* Model*::cost_interface (Model.cpp:533-542, :887-897): values[0]=cost, [1]=T, [2]=df */
+/* Model*::cost_interface (Model.cpp:533-542, :887-897, :1181-1192): values[0]=cost, [1]=T, [2]=df;
+ * DFKernel: values[2..4] = a, b, c on input */
 int umpa_hip_cost(umpa_hip_model *m, int i, int j, int shift_i, int shift_j, double *values);
 
 /* Model*::min (Model.cpp:562-578, :923-940) with the minimizer_debug fields (Optim.h:15-21)

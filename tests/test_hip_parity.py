@@ -30,7 +30,7 @@ def _variants(names):
     return out
 
 
-GPU_CASES = [c for c in ALL_CASES if c != "E_dfkernel"]
+GPU_CASES = list(ALL_CASES)
 
 
 @pytest.mark.parametrize("name,n", _variants(GPU_CASES))
@@ -71,10 +71,22 @@ def test_both_kernels_agree_with_golden(hip_ns, name, force):
                       subpx=v.get("subpx", -1))
 
 
-def test_dfkernel_reports_unsupported(hip_ns):
+def test_dfkernel_single_pixel_and_mask(hip_ns, port_ns):
+    """Kernel-dark-field model: min()/cost() entry points and the mask-weighted blur (Utils.cpp:103-117)."""
     case = Case("E_dfkernel")
-    with pytest.raises(RuntimeError, match="not built"):
-        hip_ns.UMPAModelDFKernel(case.sam, case.ref, window_size=case.Nw, max_shift=case.max_shift)
+    rng = np.random.default_rng(3)
+    mask = (rng.uniform(size=case.sam.shape) < 0.9).astype(np.float64)
+    for mk in (None, mask):
+        g = hip_ns.UMPAModelDFKernel(case.sam, case.ref, mask_list=mk, window_size=case.Nw, max_shift=case.max_shift)
+        o = port_ns.UMPAModelDFKernel(case.sam, case.ref, mask_list=mk, window_size=case.Nw, max_shift=case.max_shift)
+        assert g.padding == case.Nw + case.max_shift + 8
+        for (i, j) in [(15, 16), (20, 30), (33, 37)]:
+            np.testing.assert_allclose(g.cost(i, j, 1, -2, 0.2, 0.03, 0.1), o.cost(i, j, 1, -2, 0.2, 0.03, 0.1), rtol=1e-9)
+            np.testing.assert_allclose(g.min(i, j, 0.1, 0.0, 0.1), o.min(i, j, 0.1, 0.0, 0.1), rtol=1e-6, atol=1e-9)
+        sh = ((g.sh[0] + 2) // 3, (g.sh[1] + 2) // 3)
+        abc = np.zeros(sh + (3,)); abc[..., 0] = 0.15; abc[..., 2] = 0.1
+        got, want = g.match(abc=abc, step=3, quiet=True), o.match(abc=abc, step=3, quiet=True)
+        assert_parity(got, want, case.max_shift, "DFKernel mask=%s" % (mk is not None))
 
 
 @pytest.mark.parametrize("cfg", [

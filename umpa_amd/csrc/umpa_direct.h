@@ -38,6 +38,8 @@ struct RegionArgs {
     int* err;
     const double* cover; double thr;
     double* dbg_d; double* dbg_a; int* dbg_n;
+    double* kern; size_t kern_stride;   // DFKernel only: per-pixel 17x17 blur kernels, [tap][pixel]
+    int row_base;                       // first region row covered by `kern` (row chunking of DFKernel launches)
 };
 
 // descriptor k, read through the global address space (member-wise: a struct copy across address
@@ -56,10 +58,51 @@ __device__ __forceinline__ double pair_weight(double a, double b)   // Utils.cpp
     return a * b / (a + b + 1e-8);
 }
 
-// One cost evaluation at pixel (i,j), shift (si rows, sj cols).  KIND: 0 NoDF, 1 DF.
+#define UMPA_BLUR_HALF 8                                   // Model.h:7 KERNEL_WINDOW_SIZE
+#define UMPA_BLUR_SIDE (2 * UMPA_BLUR_HALF + 1)
+#define UMPA_BLUR_TAPS (UMPA_BLUR_SIDE * UMPA_BLUR_SIDE)
+
+// CostArgsDFKernel constructor (Model.cpp:88-117): normalised exp(-a i^2 - b i j - c j^2) on [-8,8]^2,
+// written to this pixel's column of the scratch array.
+__device__ inline void build_blur_kernel(UMPA_GLOBAL double* kern, size_t stride, double a, double b, double c)
+{
+    double norm = 0.0;
+    for (int i = -UMPA_BLUR_HALF; i <= UMPA_BLUR_HALF; i++)
+        for (int j = -UMPA_BLUR_HALF; j <= UMPA_BLUR_HALF; j++) {
+            const double g = exp(-a * i * i - b * i * j - c * j * j);            // Utils.cpp:46-50
+            kern[(size_t)((i + UMPA_BLUR_HALF) * UMPA_BLUR_SIDE + j + UMPA_BLUR_HALF) * stride] = g;
+            norm += g;
+        }
+    for (int n = 0; n < UMPA_BLUR_TAPS; n++) kern[(size_t)n * stride] /= norm;
+}
+
+// convolve / weighted_convolve (Utils.cpp:85-117) of one reference pixel with this pixel's kernel
+template <bool MASK>
+__device__ __forceinline__ double blur_at(const UMPA_GLOBAL double* img, const UMPA_GLOBAL double* wgt, int W, int i, int j,
+                                          const UMPA_GLOBAL double* kern, size_t stride)
+{
+    double acc = 0.0, wsum = 0.0;
+    for (int a = -UMPA_BLUR_HALF; a <= UMPA_BLUR_HALF; a++) {
+        const size_t row = (size_t)(i + a) * W + j;
+        for (int b = -UMPA_BLUR_HALF; b <= UMPA_BLUR_HALF; b++) {
+            const double kv = kern[(size_t)((a + UMPA_BLUR_HALF) * UMPA_BLUR_SIDE + b + UMPA_BLUR_HALF) * stride];
+            if (MASK) {
+                const double wv = wgt[row + b];
+                acc += kv * img[row + b] * wv;
+                wsum += kv * wv;
+            } else
+                acc += kv * img[row + b];
+        }
+    }
+    return MASK ? acc / wsum : acc;
+}
+
+// One cost evaluation at pixel (i,j), shift (si rows, sj cols).  KIND: 0 NoDF, 1 DF, 2 DFKernel
+// (NoDF arithmetic on a reference blurred on the fly, Model.cpp:997-1151).
 template <int KIND, bool MASK>
 __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int si, int sj,
-                                           double& cost, Fit& fit)
+                                           double& cost, Fit& fit,
+                                           const UMPA_GLOBAL double* kern = nullptr, size_t kstride = 0)
 {
     const int ms = m.ms;
     // Model.cpp:372-399 / :654-681 (flags are asymmetric in the reference; kept)
@@ -91,7 +134,8 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
             const size_t off = (size_t)a * f.W;
             for (int b = 0; b < S; b++) {
                 double w = wrow[b];
-                const double r = R[off + b];
+                const double r = KIND == 2 ? blur_at<MASK>(gp(f.ref), gp(f.mask), f.W, ri - f.pi - Nw + a, rj - f.pj - Nw + b, kern, kstride)
+                                           : R[off + b];
                 const double q = Q[off + b];
                 if (MASK) {
                     if (KIND == 1) sm += w * r;          // the ref mean is never mask-weighted (Model.cpp:804)
@@ -177,12 +221,18 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
 
     const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
     const LdsMemo<UMPA_WALK_THREADS> memo = {memo_lds + threadIdx.y * UMPA_DIRECT_BX + threadIdx.x};
+    UMPA_GLOBAL double* kern = nullptr;
+    if (KIND == 2) {                                     // Model.cpp:1228-1229: kernel from values[4..6]
+        kern = gpw(A.kern) + ((size_t)(xi - A.row_base) * A.N1 + xj);
+        const UMPA_GLOBAL double* v = gp(A.values) + px * A.nparam;
+        build_blur_kernel(kern, A.kern_stride, v[4], v[5], v[6]);
+    }
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
     while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
-        const int st = eval_direct<KIND, MASK>(m, i, j, w.req_i, w.req_j, c, fit);
+        const int st = eval_direct<KIND, MASK>(m, i, j, w.req_i, w.req_j, c, fit, kern, A.kern_stride);
         walk_feed(w, memo, st, c, fit);
     }
     double nb[16];
@@ -192,11 +242,13 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
 
 // Model*::cost_interface for one pixel (Model.cpp:533-542, :887-897): out = [cost, T, df, status]
 template <int KIND, bool MASK>
-__global__ void cost_one_kernel(ModelDev m, int i, int j, int si, int sj, double* out)
+__global__ void cost_one_kernel(ModelDev m, int i, int j, int si, int sj, double* out, double ka, double kb, double kc)
 {
     double c = 0.0;
     Fit fit = {0.0, 0.0};
-    const int st = eval_direct<KIND, MASK>(m, i, j, si, sj, c, fit);
+    UMPA_GLOBAL double* kern = gpw(out) + 8;                  // DFKernel: 289 doubles of scratch behind the results
+    if (KIND == 2) build_blur_kernel(kern, 1, ka, kb, kc);    // Model.cpp:1187-1188
+    const int st = eval_direct<KIND, MASK>(m, i, j, si, sj, c, fit, kern, 1);
     out[0] = c; out[1] = fit.t; out[2] = fit.v; out[3] = (double)st;
 }
 

@@ -72,7 +72,7 @@ struct umpa_hip_model {
     std::vector<double> win;
     double win_sum = 0.0;
     hipStream_t stream = nullptr;                  // used by the host-I/O entry points
-    DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small;
+    DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small, b_kern;
     TiledState tiled;                              // scratch of the tiled fast path
     int last_path = 0;
     bool timing = false;
@@ -165,8 +165,36 @@ void launch_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
                        m->dev(), A, nbx, nby);
 }
 
-int run_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
+int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s)
 {
+    RegionArgs A = A0;
+    A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
+    if (m->kind == UMPA_HIP_KIND_DFKERNEL) {
+        // every pixel carries its own 17x17 blur kernel (Model.cpp:88-117): 289 doubles of scratch per pixel,
+        // so the region is matched in row chunks whose scratch stays below 1 GiB
+        const size_t per_row = (size_t)UMPA_BLUR_TAPS * A.N1 * sizeof(double);
+        int rows_chunk = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_row);
+        rows_chunk = std::min(rows_chunk, A.N0);
+        if (m->b_kern.reserve(per_row * rows_chunk)) return fail(UMPA_HIP_E_NOMEM, "blur-kernel scratch");
+        for (int row0 = 0; row0 < A0.N0; row0 += rows_chunk) {
+            RegionArgs C = A0;
+            const size_t px0 = (size_t)row0 * A0.N1;
+            C.org0 = A0.org0 + A0.step0 * row0;
+            C.N0 = std::min(rows_chunk, A0.N0 - row0);
+            C.values = A0.values + px0 * A0.nparam;
+            C.uv = A0.uv ? A0.uv + 2 * px0 : nullptr;
+            C.err = A0.err + px0;
+            C.cover = A0.cover ? A0.cover + px0 : nullptr;
+            C.dbg_d = A0.dbg_d ? A0.dbg_d + 25 * px0 : nullptr;
+            C.dbg_a = A0.dbg_a ? A0.dbg_a + 16 * px0 : nullptr;
+            C.dbg_n = A0.dbg_n ? A0.dbg_n + px0 : nullptr;
+            C.kern = (double*)m->b_kern.p; C.kern_stride = (size_t)C.N0 * C.N1; C.row_base = 0;
+            if (m->has_mask) launch_direct<2, true>(m, C, s); else launch_direct<2, false>(m, C, s);
+            HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
+        }
+        m->last_path = 1;
+        return 0;
+    }
     if (m->kind == UMPA_HIP_KIND_NODF) { if (m->has_mask) launch_direct<0, true>(m, A, s); else launch_direct<0, false>(m, A, s); }
     else { if (m->has_mask) launch_direct<1, true>(m, A, s); else launch_direct<1, false>(m, A, s); }
     HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
@@ -177,7 +205,7 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
 // Can the tiled fast path take this region?  (see umpa_tiled.h for what it covers)
 bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
 {
-    if (m->has_mask) return false;
+    if (m->has_mask || m->kind == UMPA_HIP_KIND_DFKERNEL) return false;
     for (int k = 0; k < m->Na; k++) {
         if (m->pos[2 * k] || m->pos[2 * k + 1]) return false;
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
@@ -227,8 +255,8 @@ umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const
                                 double* const* mask, const int* pos, int Nw, const double* win,
                                 int max_shift, int padding, int device, int flags)
 {
-    if (kind != UMPA_HIP_KIND_NODF && kind != UMPA_HIP_KIND_DF) {
-        fail(UMPA_HIP_E_UNSUPPORTED, "model kind %d is not built in the HIP library yet", kind);
+    if (kind != UMPA_HIP_KIND_NODF && kind != UMPA_HIP_KIND_DF && kind != UMPA_HIP_KIND_DFKERNEL) {
+        fail(UMPA_HIP_E_ARG, "unknown model kind %d", kind);
         return nullptr;
     }
     if (Na <= 0 || !dims || !sam || !ref || !pos || !win || Nw < 0 || max_shift < 0 || padding < Nw + max_shift) {
@@ -309,7 +337,7 @@ void umpa_hip_destroy(umpa_hip_model* m)
     for (auto e : m->event_pool) (void)hipEventDestroy(e);
     tiled_release(m->tiled);
     m->b_values.release(); m->b_uv.release(); m->b_err.release(); m->b_cover.release();
-    m->b_dd.release(); m->b_da.release(); m->b_dn.release(); m->b_small.release();
+    m->b_dd.release(); m->b_da.release(); m->b_dn.release(); m->b_small.release(); m->b_kern.release();
     if (m->d_desc) (void)hipFree(m->d_desc);
     if (m->d_win) (void)hipFree(m->d_win);
     if (m->d_frames_blob) (void)hipFree(m->d_frames_blob);
@@ -388,13 +416,15 @@ int umpa_hip_cost(umpa_hip_model* m, int i, int j, int si, int sj, double* value
     if (!m || !values) return fail(UMPA_HIP_E_ARG, "null argument");
     (void)pixel_in_frames;
     HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
-    if (m->b_small.reserve(64 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
+    if (m->b_small.reserve(512 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
     double* d = (double*)m->b_small.p;
     const ModelDev dv = m->dev();
-    if (m->kind == 0) { if (m->has_mask) hipLaunchKernelGGL((cost_one_kernel<0, true>), 1, 1, 0, m->stream, dv, i, j, si, sj, d);
-                        else hipLaunchKernelGGL((cost_one_kernel<0, false>), 1, 1, 0, m->stream, dv, i, j, si, sj, d); }
-    else { if (m->has_mask) hipLaunchKernelGGL((cost_one_kernel<1, true>), 1, 1, 0, m->stream, dv, i, j, si, sj, d);
-           else hipLaunchKernelGGL((cost_one_kernel<1, false>), 1, 1, 0, m->stream, dv, i, j, si, sj, d); }
+    const double ka = m->kind == 2 ? values[2] : 0.0, kb = m->kind == 2 ? values[3] : 0.0, kc = m->kind == 2 ? values[4] : 0.0;
+#define UMPA_COST_LAUNCH(K, M) hipLaunchKernelGGL((cost_one_kernel<K, M>), 1, 1, 0, m->stream, dv, i, j, si, sj, d, ka, kb, kc)
+    if (m->kind == 0) { if (m->has_mask) UMPA_COST_LAUNCH(0, true); else UMPA_COST_LAUNCH(0, false); }
+    else if (m->kind == 1) { if (m->has_mask) UMPA_COST_LAUNCH(1, true); else UMPA_COST_LAUNCH(1, false); }
+    else { if (m->has_mask) UMPA_COST_LAUNCH(2, true); else UMPA_COST_LAUNCH(2, false); }
+#undef UMPA_COST_LAUNCH
     HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
     double h[4];
     HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream), UMPA_HIP_E_DEVICE);
@@ -417,7 +447,7 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
                           double* dbg_d, double* dbg_a, int* dbg_ncalls, int flags, void* stream)
 {
     if (!m || !values || !err) return fail(UMPA_HIP_E_ARG, "null argument");
-    if (nparam < (m->kind == 1 ? 5 : 4)) return fail(UMPA_HIP_E_ARG, "nparam=%d too small for this model", nparam);
+    if (nparam < (m->kind == 1 ? 5 : m->kind == 2 ? 7 : 4)) return fail(UMPA_HIP_E_ARG, "nparam=%d too small for this model", nparam);
     if (int rc = check_region(m, start0, step0, N0, start1, step1, N1)) return rc;
     HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
     const size_t n = (size_t)N0 * N1;
@@ -425,7 +455,7 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
     RegionArgs A;
     A.org0 = m->padding + start0; A.step0 = step0; A.N0 = N0;       // model.pyx:482-483
     A.org1 = m->padding + start1; A.step1 = step1; A.N1 = N1;
-    A.nparam = nparam; A.thr = cover_threshold;
+    A.nparam = nparam; A.thr = cover_threshold; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
 
     if (flags & UMPA_HIP_F_DEVICE_IO) {
         A.values = values; A.uv = uv; A.err = err; A.cover = covermap;
@@ -475,30 +505,30 @@ int umpa_hip_min(umpa_hip_model* m, int i, int j, double* values, double* uv, do
 {
     if (!m || !values) return fail(UMPA_HIP_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
-    const int np = m->kind == 1 ? 5 : 4;
-    if (m->b_small.reserve(64 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
-    double* d = (double*)m->b_small.p;                 // [0..4] values, [5..6] uv, [7] err(int), [8] ncalls(int), [9..33] d, [34..49] a
-    double h[50];
+    const int np = m->kind == 1 ? 5 : m->kind == 2 ? 7 : 4;
+    if (m->b_small.reserve(512 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
+    double* d = (double*)m->b_small.p;                 // [0..7) values, [8..9] uv, [10] err(int), [11] ncalls(int), [12..37) d, [37..53) a
+    double h[53];
     memset(h, 0, sizeof(h));
     for (int q = 0; q < np; q++) h[q] = values[q];
-    if (uv) { h[5] = uv[0]; h[6] = uv[1]; }
+    if (uv) { h[8] = uv[0]; h[9] = uv[1]; }
     hipStream_t s = m->stream;
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
     RegionArgs A;
     A.org0 = i; A.step0 = 1; A.N0 = 1; A.org1 = j; A.step1 = 1; A.N1 = 1;      // Model::min takes absolute coordinates
-    A.values = d; A.nparam = np; A.uv = d + 5; A.err = (int*)(d + 7); A.cover = nullptr; A.thr = 0.0;
-    A.dbg_n = (int*)(d + 8); A.dbg_d = d + 9; A.dbg_a = d + 34;
+    A.values = d; A.nparam = np; A.uv = d + 8; A.err = (int*)(d + 10); A.cover = nullptr; A.thr = 0.0;
+    A.dbg_n = (int*)(d + 11); A.dbg_d = d + 12; A.dbg_a = d + 37; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
     if (int rc = run_direct(m, A, s)) return rc;
     HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
     HIP_TRY(hipStreamSynchronize(s), UMPA_HIP_E_DEVICE);
     for (int q = 0; q < np; q++) values[q] = h[q];
-    if (uv) { uv[0] = h[5]; uv[1] = h[6]; }
+    if (uv) { uv[0] = h[8]; uv[1] = h[9]; }
     int e, nc;
-    memcpy(&e, &h[7], sizeof(int));
-    memcpy(&nc, &h[8], sizeof(int));
+    memcpy(&e, &h[10], sizeof(int));
+    memcpy(&nc, &h[11], sizeof(int));
     if (ncalls) *ncalls = nc;
-    if (dbg_d) memcpy(dbg_d, h + 9, 25 * sizeof(double));
-    if (dbg_a) memcpy(dbg_a, h + 34, 16 * sizeof(double));
+    if (dbg_d) memcpy(dbg_d, h + 12, 25 * sizeof(double));
+    if (dbg_a) memcpy(dbg_a, h + 37, 16 * sizeof(double));
     return e;          // only the ok bit survives the region kernel, as in the Cython loop (model.pyx:487)
 }
 

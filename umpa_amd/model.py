@@ -524,10 +524,9 @@ class UMPAModelDF(UMPAModelBase):
 
 
 class UMPAModelDFKernel(UMPAModelBase):
-    """Mirror of ``UMPAModelDFKernel`` (``model.pyx:899-997``).
-
-    The kernel-dark-field cost is SURVEY.md row (f3) and is not built in the HIP library yet:
-    construction raises (the library reports UMPA_HIP_E_UNSUPPORTED)."""
+    """Mirror of ``UMPAModelDFKernel`` (``model.pyx:899-997``): the reference blurred on the fly by a
+    per-pixel 17x17 Gaussian ``exp(-a i^2 - b ij - c j^2)``; ``abc`` is an input.  Runs on the general
+    direct kernel (289 taps per window pixel, as heavy as in the reference)."""
     Nparam = 7
     safe_crop = 8
     _kind = KIND_DFKERNEL
