@@ -333,9 +333,10 @@ class UMPAModelBase:
         err = np.zeros(sh, dtype=np.int32)
         result = {}
         dd = da = dn = None
-        if self.debug:
-            dd = np.zeros(sh + (25,), dtype=NPDOUBLE)
-            da = np.zeros(sh + (16,), dtype=NPDOUBLE)
+        if self.debug:                                              # debug = "ncalls": only the evaluation counts
+            if self.debug != "ncalls":
+                dd = np.zeros(sh + (25,), dtype=NPDOUBLE)
+                da = np.zeros(sh + (16,), dtype=NPDOUBLE)
             dn = np.zeros(sh, dtype=np.int32)
 
         vp = lambda a: a.ctypes.data if a is not None else None
@@ -353,8 +354,9 @@ class UMPAModelBase:
         result['values'] = values
         result['err'] = err
         if self.debug:
-            result['debug_d'] = dd
-            result['debug_a'] = da
+            if dd is not None:
+                result['debug_d'] = dd
+                result['debug_a'] = da
             result['debug_Ncalls'] = dn
         return result
 
