@@ -537,12 +537,12 @@ inline void tiled_release(TiledState& st)
 
 inline int pick_ub(int UJ)
 {
-    // batch width over the column shifts: least padding, then the widest
-    int best = 5, waste = 1 << 30;
-    const int cand[3] = {9, 7, 5};
-    for (int q = 0; q < 3; q++) {
-        const int ub = cand[q], w = ((UJ + ub - 1) / ub) * ub - UJ;
-        if (w < waste) { waste = w; best = ub; }
+    // batch width over the column shifts: fewest batches (each batch re-stages the frames), then least padding
+    int best = 5, best_nb = 1 << 30, best_waste = 1 << 30;
+    const int cand[4] = {9, 8, 7, 5};
+    for (int q = 0; q < 4; q++) {
+        const int ub = cand[q], nb = (UJ + ub - 1) / ub, w = nb * ub - UJ;
+        if (nb < best_nb || (nb == best_nb && w < best_waste)) { best = ub; best_nb = nb; best_waste = w; }
     }
     return best;
 }
@@ -570,6 +570,10 @@ inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A,
 {
     if (ub == 9) {
         if constexpr (CorrCfg<NW, 9>::OK) return launch_corr<NW, 9>(dev, A, sep, s);
+        ub = 8;
+    }
+    if (ub == 8) {
+        if constexpr (CorrCfg<NW, 8>::OK) return launch_corr<NW, 8>(dev, A, sep, s);
         ub = 7;
     }
     if (ub == 7) {
