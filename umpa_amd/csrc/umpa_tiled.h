@@ -400,6 +400,7 @@ struct ReplayArgs {
     const double* table;
     size_t slot_stride;
     int row0, rows;           // region rows covered by the table
+    int ablate;               // diagnostics only (UMPA_HIP_ABLATE_REPLAY): 1 = 18 fixed lookups instead of the walk, 2 = no sub-pixel fit
 };
 
 #define UMPA_KFIX 16          // frames whose fixed-window map value is kept in registers by replay_walk
@@ -477,6 +478,16 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
     const LdsMemo<UMPA_WALK_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
+    if (R.ablate & 1) {                                             // diagnostics: the lookups without the walk
+        double csum = 0.0;
+        Fit fit = w.live;
+        for (int n = 0; n < 18; n++) {
+            double c = 0.0;
+            eval_lookup<KIND>(m, M, R, m.ref_mode, i, j, tpx, (n % 5) - 2, (n / 5) - 2, fixed, c, fit);
+            csum += c;
+        }
+        w.out = csum; w.live = fit; w.phase = PH_DONE; w.status = 1;
+    }
     while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
@@ -484,7 +495,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
         walk_feed(w, memo, st, c, fit);
     }
     double nb[16];
-    walk_finish(w, memo, m.subpx, nb);
+    walk_finish(w, memo, (R.ablate & 2) ? 0 : m.subpx, nb);
     if (KIND == 1 && (w.live.t != 0.0 || w.live.v != 0.0))          // eval_lookup left K in the v slot; (0,0) = never evaluated
         w.live.v = w.live.v / w.live.t;                             // Model.cpp:854
     store_pixel(A, px, KIND, w, memo, nb);
@@ -685,6 +696,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
 
         ReplayArgs R;
         R.table = st.table; R.slot_stride = CA.slot_stride; R.row0 = row0; R.rows = rows;
+        { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
         dim3 blk(64, 4), grd((A.N1 + 63) / 64, (rows + 3) / 4);
         tic(4);
         if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1>), grd, blk, 0, s, dev, M, R, A);
