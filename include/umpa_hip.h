@@ -52,6 +52,7 @@ extern "C" {
 #define UMPA_HIP_F_DEVICE_IO      1  /* values/uv/err/covermap/debug pointers are device pointers; call is async on `stream` */
 #define UMPA_HIP_F_FORCE_DIRECT   2  /* use the general direct kernel even where the tiled fast path applies */
 #define UMPA_HIP_F_FORCE_TILED    4  /* fail with E_UNSUPPORTED instead of silently using the direct kernel */
+#define UMPA_HIP_F_PLANAR         8  /* values is [nparam][N0*N1] (one plane per map) instead of the reference's [N0*N1][nparam] */
 
 typedef struct umpa_hip_model umpa_hip_model;
 

@@ -34,6 +34,7 @@ struct RegionArgs {
     int org0, step0, N0;       // pixel (xi,xj) sits at frame coords (org0+step0*xi, org1+step1*xj)
     int org1, step1, N1;
     double* values; int nparam;
+    size_t v_px, v_k;          // element (pixel px, parameter k) of `values` sits at px*v_px + k*v_k (interleaved: nparam,1; planar: 1,N0*N1)
     double* uv;                // may be NULL: start at (0,0), result not stored
     int* err;
     const double* cover; double thr;
@@ -179,12 +180,12 @@ template <class Memo>
 __device__ __forceinline__ void store_pixel(const RegionArgs& A, size_t px, int kind, const Walk& w,
                                             Memo memo, const double* nb)
 {
-    UMPA_GLOBAL double* v = gpw(A.values) + px * A.nparam;
+    UMPA_GLOBAL double* v = gpw(A.values) + px * A.v_px;
     v[0] = w.out;
-    v[1] = w.live.t;
-    v[2] = w.uv1;
-    v[3] = w.uv0;
-    if (kind == 1) v[4] = w.live.v;
+    v[A.v_k] = w.live.t;
+    v[2 * A.v_k] = w.uv1;
+    v[3 * A.v_k] = w.uv0;
+    if (kind == 1) v[4 * A.v_k] = w.live.v;
     if (A.uv) { gpw(A.uv)[2 * px] = w.uv0; gpw(A.uv)[2 * px + 1] = w.uv1; }
     gpw(A.err)[px] = w.status & UMPA_ST_OK;
     if (A.dbg_n) gpw(A.dbg_n)[px] = w.n;
@@ -224,8 +225,8 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
     UMPA_GLOBAL double* kern = nullptr;
     if (KIND == 2) {                                     // Model.cpp:1228-1229: kernel from values[4..6]
         kern = gpw(A.kern) + ((size_t)(xi - A.row_base) * A.N1 + xj);
-        const UMPA_GLOBAL double* v = gp(A.values) + px * A.nparam;
-        build_blur_kernel(kern, A.kern_stride, v[4], v[5], v[6]);
+        const UMPA_GLOBAL double* v = gp(A.values) + px * A.v_px;
+        build_blur_kernel(kern, A.kern_stride, v[4 * A.v_k], v[5 * A.v_k], v[6 * A.v_k]);
     }
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);

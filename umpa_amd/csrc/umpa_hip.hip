@@ -181,7 +181,7 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s)
             const size_t px0 = (size_t)row0 * A0.N1;
             C.org0 = A0.org0 + A0.step0 * row0;
             C.N0 = std::min(rows_chunk, A0.N0 - row0);
-            C.values = A0.values + px0 * A0.nparam;
+            C.values = A0.values + px0 * A0.v_px;
             C.uv = A0.uv ? A0.uv + 2 * px0 : nullptr;
             C.err = A0.err + px0;
             C.cover = A0.cover ? A0.cover + px0 : nullptr;
@@ -456,6 +456,8 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
     A.org0 = m->padding + start0; A.step0 = step0; A.N0 = N0;       // model.pyx:482-483
     A.org1 = m->padding + start1; A.step1 = step1; A.N1 = N1;
     A.nparam = nparam; A.thr = cover_threshold; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
+    const bool planar = (flags & UMPA_HIP_F_PLANAR) != 0;
+    A.v_px = planar ? 1 : (size_t)nparam; A.v_k = planar ? n : 1;
 
     if (flags & UMPA_HIP_F_DEVICE_IO) {
         A.values = values; A.uv = uv; A.err = err; A.cover = covermap;
@@ -467,9 +469,13 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
     hipStream_t s = m->stream;
     if (m->b_values.reserve(n * nparam * sizeof(double)) || m->b_err.reserve(n * sizeof(int)))
         return fail(UMPA_HIP_E_NOMEM, "output buffers (%zu pixels)", n);
-    // values and err start from the caller's arrays (zeros in the reference, model.pyx:455,468)
-    HIP_TRY(hipMemcpyAsync(m->b_values.p, values, n * nparam * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
-    HIP_TRY(hipMemcpyAsync(m->b_err.p, err, n * sizeof(int), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+    // values and err start from the caller's arrays (zeros in the reference, model.pyx:455,468).  They only matter
+    // where the kernel reads them (DFKernel's a,b,c) or leaves them alone (pixels skipped by the coverage test):
+    // otherwise every element is overwritten and the upload is skipped.
+    if (m->kind == UMPA_HIP_KIND_DFKERNEL || covermap) {
+        HIP_TRY(hipMemcpyAsync(m->b_values.p, values, n * nparam * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+        HIP_TRY(hipMemcpyAsync(m->b_err.p, err, n * sizeof(int), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+    }
     A.values = (double*)m->b_values.p; A.err = (int*)m->b_err.p;
     A.uv = nullptr; A.cover = nullptr; A.dbg_d = nullptr; A.dbg_a = nullptr; A.dbg_n = nullptr;
     if (uv) {
@@ -516,7 +522,7 @@ int umpa_hip_min(umpa_hip_model* m, int i, int j, double* values, double* uv, do
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
     RegionArgs A;
     A.org0 = i; A.step0 = 1; A.N0 = 1; A.org1 = j; A.step1 = 1; A.N1 = 1;      // Model::min takes absolute coordinates
-    A.values = d; A.nparam = np; A.uv = d + 8; A.err = (int*)(d + 10); A.cover = nullptr; A.thr = 0.0;
+    A.values = d; A.nparam = np; A.v_px = np; A.v_k = 1; A.uv = d + 8; A.err = (int*)(d + 10); A.cover = nullptr; A.thr = 0.0;
     A.dbg_n = (int*)(d + 11); A.dbg_d = d + 12; A.dbg_a = d + 37; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
     if (int rc = run_direct(m, A, s)) return rc;
     HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);

@@ -306,6 +306,7 @@ class UMPAModelBase:
         self._check_range(s0, s1, N0, N1)
         sh = (N0, N1)
         shp = (N0, N1, self.Nparam)
+        planar = False
 
         if self._trivial_coverage():
             covermap = None                                         # == Na everywhere: nothing is skipped
@@ -322,6 +323,11 @@ class UMPAModelBase:
                 raise RuntimeError("Input values have the wrong type: "
                                    "%s, should be %s" % (input_values.dtype, np.float64))
             values = np.ascontiguousarray(input_values)
+        elif self._lib.is_hip:
+            # one plane per map: the device writes the result maps directly (no host-side de-interleaving)
+            planar = True
+            shp = (self.Nparam, N0, N1)
+            values = np.empty(shp, dtype=NPDOUBLE) if covermap is None else np.zeros(shp, dtype=NPDOUBLE)
         else:
             values = np.zeros(shp, dtype=NPDOUBLE)
 
@@ -330,7 +336,7 @@ class UMPAModelBase:
             uv = np.zeros((N0, N1, 2), dtype=NPDOUBLE)
             uv[:, :, 0] = dxdy[0]
             uv[:, :, 1] = dxdy[1]
-        err = np.zeros(sh, dtype=np.int32)
+        err = np.empty(sh, dtype=np.int32) if (covermap is None and self._lib.is_hip) else np.zeros(sh, dtype=np.int32)
         result = {}
         dd = da = dn = None
         if self.debug:                                              # debug = "ncalls": only the evaluation counts
@@ -343,7 +349,7 @@ class UMPAModelBase:
         args = [self._handle, s0[0], s0[2], N0, s1[0], s1[2], N1, vp(values), self.Nparam, vp(uv), vp(err),
                 vp(covermap), float(thr), vp(dd), vp(da), vp(dn)]
         if self._lib.is_hip:
-            args += [self._match_flags(), None]
+            args += [self._match_flags() | (_lib.F_PLANAR if planar else 0), None]
         else:
             if uv is None:
                 uv = np.zeros((N0, N1, 2), dtype=NPDOUBLE)
@@ -352,6 +358,7 @@ class UMPAModelBase:
         self._lib.check(self._lib.match_region(*args), "match_region")
 
         result['values'] = values
+        result['_planar'] = planar
         result['err'] = err
         if self.debug:
             if dd is not None:
@@ -466,12 +473,14 @@ class UMPAModelBase:
     # -- packing shared by the subclasses (model.pyx:815-822, :881-889)
     def _unpack(self, result, with_df):
         values = result.pop('values')
-        result['f'] = values[:, :, 0].copy()
-        result['T'] = values[:, :, 1].copy()
-        result['dx'] = values[:, :, 2].copy()
-        result['dy'] = values[:, :, 3].copy()
+        if result.pop('_planar', False):
+            planes = values                                         # written plane by plane on the device
+        else:
+            # one pass over the interleaved array instead of one strided copy per map
+            planes = np.ascontiguousarray(np.moveaxis(values[:, :, :5 if with_df else 4], 2, 0))
+        result['f'], result['T'], result['dx'], result['dy'] = planes[0], planes[1], planes[2], planes[3]
         if with_df:
-            result['df'] = values[:, :, 4].copy()
+            result['df'] = planes[4]
         return result
 
 
