@@ -73,6 +73,12 @@ umpa_hip_model *umpa_hip_create(int kind, int Na, const int *dims,
                                 const int *pos, int Nw, const double *win,
                                 int max_shift, int padding, int device, int flags);
 
+/* Replace the contents of the resident sample and/or reference stacks (same shapes; NULL = keep).
+ * No counterpart in the reference, whose models borrow host pointers (model.pyx:123-129): there a caller
+ * such as umpa_multi.py:149 builds a new model per projection.  Here the reference stack can stay in HBM
+ * while projections stream through. */
+int umpa_hip_update_frames(umpa_hip_model *m, double *const *sam, double *const *ref);
+
 /* ~ModelBase (Model.cpp:224) */
 void umpa_hip_destroy(umpa_hip_model *m);
 

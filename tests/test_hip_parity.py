@@ -192,3 +192,27 @@ def test_pixels_are_independent_at_full_width(hip_ns):
     roi = m.match(ROI=((10, 200, 2), (1000, 2030, 5)), quiet=True)
     for k in ("f", "T", "dx", "dy", "df", "err"):
         np.testing.assert_array_equal(roi[k], full[k][10:200:2, 1000:2030:5])
+
+
+def test_update_frames_and_projection_farm(hip_ns):
+    """Extension used by the projection farm: swap the sample stack, keep the reference resident."""
+    from umpa_amd.farm import ProjectionFarm
+    from umpa_amd.synth import make_stack
+    Nw, ms = 3, 4
+    stacks = [make_stack(80, 96, 4, ms, df=True, seed=10 * p, amplitude=1.5) for p in range(3)]
+    ref = stacks[0][1]
+    sams = {p: np.ascontiguousarray(stacks[p][0]) for p in range(3)}
+    want = {p: hip_ns.UMPAModelDF(sams[p], ref, window_size=Nw, max_shift=ms).match(quiet=True) for p in range(3)}
+    m = hip_ns.UMPAModelDF(sams[0], ref, window_size=Nw, max_shift=ms)
+    for p in (1, 2, 0):
+        m.update_frames(sam_list=sams[p])
+        got = m.match(quiet=True)
+        for k in ("f", "T", "dx", "dy", "df", "err"):
+            np.testing.assert_array_equal(got[k], want[p][k])
+    with pytest.raises(RuntimeError, match="shapes"):
+        m.update_frames(sam_list=sams[0][:, :-2])
+    with ProjectionFarm(ref, Nw, ms, devices=[0]) as farm:
+        res = dict(farm.map(sams.items()))
+    for p in range(3):
+        for k in ("f", "T", "dx", "dy", "df", "err"):
+            np.testing.assert_array_equal(res[p][k], want[p][k])

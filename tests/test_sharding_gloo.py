@@ -92,3 +92,22 @@ def test_slab_bounds_partition():
     # BASELINE config C4: 8172 output rows over 8 GPUs -> 4 x 1022 + 4 x 1021, 10 halo rows each side
     assert [slab_bounds(8172, 8, g)[1] - slab_bounds(8172, 8, g)[0] for g in range(8)] == [1022] * 4 + [1021] * 4
     assert input_rows(8172, 10, 8, 3) == (3 * 1022, 4 * 1022 + 20)
+
+
+def test_projection_farm_on_cpu_workers():
+    """umpa_amd.farm (config C5's pattern: independent projections, shared reference) with two CPU workers."""
+    from oracle import cpu_model
+    from umpa_amd.farm import ProjectionFarm
+    from umpa_amd.synth import make_stack
+    cpu_model.native("port")
+    Nw, ms = 2, 3
+    stacks = [make_stack(40, 44, 3, ms, df=True, seed=100 * p, amplitude=1.0) for p in range(3)]
+    ref = stacks[0][1]
+    sams = {p: np.ascontiguousarray(0.9 * stacks[p][0]) for p in range(3)}
+    with ProjectionFarm(ref, Nw, ms, devices=[None, None], model=("oracle.cpu_model", "port.UMPAModelDF")) as farm:
+        got = dict(farm.map(sams.items(), num_threads=1))
+    assert sorted(got) == [0, 1, 2]
+    for p in range(3):
+        want = cpu_model.port.UMPAModelDF(sams[p], ref, window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
+        for k in ("f", "T", "dx", "dy", "df", "err"):
+            np.testing.assert_array_equal(got[p][k], want[k])

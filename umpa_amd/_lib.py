@@ -29,6 +29,7 @@ HIP_SYMBOLS = [
     "device_count", "last_error", "version", "create", "destroy", "set_window", "set_subpx",
     "set_reference_shift", "coverage", "coverage_region", "cost", "min", "match_region",
     "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "last_path",
+    "update_frames",
 ]
 
 
@@ -77,6 +78,7 @@ class Native:
             f("timing_collect", C.c_int, [C.c_void_p])
             f("timing_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), _dp, _ip])
             f("last_path", C.c_int, [C.c_void_p])
+            f("update_frames", C.c_int, [C.c_void_p, _dpp, _dpp])
         else:
             f("spmin", C.c_double, [_dp, _dp])
             f("spmin_quad", C.c_double, [_dp, _dp])

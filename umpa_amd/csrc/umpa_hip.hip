@@ -328,6 +328,20 @@ umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const
     return m;
 }
 
+int umpa_hip_update_frames(umpa_hip_model* m, double* const* sam, double* const* ref)
+{
+    if (!m) return fail(UMPA_HIP_E_ARG, "null model");
+    if (!m->owns_frames) return fail(UMPA_HIP_E_ARG, "the model borrows device frames; update them in place instead");
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    for (int k = 0; k < m->Na; k++) {
+        const size_t n = (size_t)m->dims[2 * k] * m->dims[2 * k + 1] * sizeof(double);
+        if (sam) HIP_TRY(hipMemcpyAsync(m->d_sam[k], sam[k], n, hipMemcpyHostToDevice, m->stream), UMPA_HIP_E_DEVICE);
+        if (ref) HIP_TRY(hipMemcpyAsync(m->d_ref[k], ref[k], n, hipMemcpyHostToDevice, m->stream), UMPA_HIP_E_DEVICE);
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream), UMPA_HIP_E_DEVICE);
+    return 0;
+}
+
 void umpa_hip_destroy(umpa_hip_model* m)
 {
     if (!m) return;

@@ -159,6 +159,27 @@ class UMPAModelBase:
         if h:
             self._lib.destroy(h)
 
+    def update_frames(self, sam_list=None, ref_list=None):
+        """Swap in new sample and/or reference stacks of the same shapes without rebuilding the model
+        (extension: the reference rebuilds a model per projection, ``umpa_multi.py:149``).  On the GPU
+        the untouched stack stays resident."""
+        new_sam = self._prepare_frames(sam_list) if sam_list is not None else None
+        new_ref = self._prepare_frames(ref_list) if ref_list is not None else None
+        for new in (new_sam, new_ref):
+            if new is not None and [tuple(x.shape) for x in new] != [tuple(x.shape) for x in self._sam]:
+                raise RuntimeError('update_frames needs stacks of the shapes the model was built with.')
+        if not self._lib.is_hip or hasattr(self._sam[0], "data_ptr"):
+            raise RuntimeError('update_frames needs a model that owns device copies of host frames.')
+        fs_s = _lib.FrameSet(new_sam) if new_sam is not None else None
+        fs_r = _lib.FrameSet(new_ref) if new_ref is not None else None
+        self._lib.check(self._lib.update_frames(self._handle, fs_s.table if fs_s else None,
+                                                fs_r.table if fs_r else None), "update_frames")
+        if new_sam is not None:
+            self._sam, self._sam_list = new_sam, sam_list
+        if new_ref is not None:
+            self._ref, self._ref_list = new_ref, ref_list
+        self._fs = (_lib.FrameSet(self._sam), _lib.FrameSet(self._ref), self._fs[2])
+
     # -- input handling
     def _check_contiguous(self, a):
         if any(not (x.is_contiguous() if hasattr(x, "is_contiguous") else x.flags.c_contiguous) for x in a):
