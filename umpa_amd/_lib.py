@@ -11,8 +11,6 @@ only the test-suite binds those, through ``oracle/cpu_model.py``.)
 import ctypes as C
 import os
 
-import numpy as np
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "libumpa_hip.so")
 
@@ -142,7 +140,3 @@ class FrameSet:
             else:
                 self.table[k] = a.ctypes.data_as(_dp)
 
-
-def as_c(a, dtype):
-    a = np.ascontiguousarray(a, dtype=dtype)
-    return a

@@ -417,18 +417,11 @@ int umpa_hip_coverage(umpa_hip_model* m, double* out, int i, int j)
     return UMPA_HIP_ST_OK;
 }
 
-static int pixel_in_frames(const umpa_hip_model* m, int i, int j)
-{
-    // a single-pixel call must keep every window inside the frames that cover the pixel; pixels no frame
-    // covers are harmless (all frames skipped).  Only reject coordinates that could index before a frame.
-    (void)m; (void)i; (void)j;
-    return 1;
-}
-
+// Single-pixel calls accept any (i, j): a frame contributes only if the pixel lies `padding` inside it
+// (the coverage test inside the kernels), which keeps every window read within that frame.
 int umpa_hip_cost(umpa_hip_model* m, int i, int j, int si, int sj, double* values)
 {
     if (!m || !values) return fail(UMPA_HIP_E_ARG, "null argument");
-    (void)pixel_in_frames;
     HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
     if (m->b_small.reserve(512 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "scratch");
     double* d = (double*)m->b_small.p;
