@@ -104,17 +104,32 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
 #pragma unroll
         for (int o = 0; o < C::CB; o++) { acc[q][o] = 0.0; acc2[q][o] = 0.0; }
 
-    for (int k = 0; k < m.Na; k++) {
-        const FrameDesc f = load_frame(m.frames, k);
-        __syncthreads();
-        // stage the raw patches, transposed; global reads coalesced along columns
-        for (int it = tid; it < C::Q * C::Q; it += C::NT) {
-            const int c = it % C::Q, r = it / C::Q;
-            const int gr = min(r0 - NW + r, f.H - 1), gc = min(c0 - NW + c, f.W - 1);
-            const size_t g = (size_t)gr * f.W + gc;
-            rawS[c * C::QP + r] = gp(f.sam)[g];
-            rawR[c * C::QP + r] = gp(f.ref)[g];
+    // staging slots of this thread: compile-time count, so the frame k+1 can wait in registers while frame k is filtered
+    constexpr int NS = (C::Q * C::Q + C::NT - 1) / C::NT;
+    int s_lds[NS], s_g[NS];
+    {
+        const int Hf = gp(m.frames)->H, Wf = gp(m.frames)->W;          // tiled path: all frames share one shape
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            const int it = tid + n * C::NT, c = it % C::Q, r = it / C::Q;
+            s_lds[n] = it < C::Q * C::Q ? c * C::QP + r : -1;
+            s_g[n] = min(r0 - NW + r, Hf - 1) * Wf + min(c0 - NW + c, Wf - 1);
         }
+    }
+    double ps[NS], pr[NS];
+    auto fetch = [&](int k) {
+        const FrameDesc f = load_frame(m.frames, k);
+#pragma unroll
+        for (int n = 0; n < NS; n++) { ps[n] = gp(f.sam)[s_g[n]]; pr[n] = gp(f.ref)[s_g[n]]; }
+    };
+    fetch(0);
+    for (int k = 0; k < m.Na; k++) {
+        __syncthreads();
+        // stage the raw patches, transposed; the global reads (issued one frame ahead) are coalesced along columns
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+            if (s_lds[n] >= 0) { rawS[s_lds[n]] = ps[n]; rawR[s_lds[n]] = pr[n]; }
+        if (k + 1 < m.Na) fetch(k + 1);
         __syncthreads();
         // H stage (along columns): items (which, cb, r), r fastest: 2 x 4 x Q
         for (int it = tid; it < 2 * 4 * C::Q; it += C::NT) {
