@@ -204,14 +204,14 @@ struct CorrCfg {
     static constexpr int QP = Q | 1;                      // odd row stride of the transposed tiles
     static constexpr int NQB = NT / Q;                    // q column-blocks handled side by side
     static constexpr int QB = (Q + NQB - 1) / NQB;        // q columns per thread
-    static constexpr int AC = NQB * QB;                   // allocated A columns (>= Q)
-    static constexpr int BC = AC + UB - 1;                // allocated B columns
-    static constexpr int BW = Q + UB - 1;                 // B columns actually staged
-    static constexpr int AFR = AC * QP, BFR = BC * QP;    // doubles per staged frame
+    static constexpr int AC = NQB * QB;                   // columns the product threads address (>= Q; the excess is never stored)
+    static constexpr int BW = Q + UB - 1;                 // B columns staged
+    static constexpr int AFR = Q * QP, BFR = BW * QP;     // doubles per staged frame: packed, A then B
     static constexpr int FRAME = AFR + BFR;
+    static constexpr int SLACK = (AC - Q) * QP;           // threads of the padding columns read this far past a frame
     static constexpr int PPL = Q * QP;                    // one product plane
-    static constexpr int FCH = (UMPA_LDS_BUDGET / 8) / FRAME;           // frames staged per barrier
-    static constexpr int LDS_DOUBLES = (FCH * FRAME > UB * PPL) ? FCH * FRAME : UB * PPL;
+    static constexpr int FCH = (UMPA_LDS_BUDGET / 8 - SLACK) / FRAME;   // frames staged per barrier
+    static constexpr int LDS_DOUBLES = (FCH * FRAME + SLACK > UB * PPL) ? FCH * FRAME + SLACK : UB * PPL;
     static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
     static constexpr int CB = 8;                          // outputs per filter item
     static constexpr int HITEMS = UB * (T / CB) * Q, HROUNDS = (HITEMS + NT - 1) / NT;
