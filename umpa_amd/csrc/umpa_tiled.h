@@ -577,12 +577,14 @@ template <int NW, int UB>
 inline hipError_t launch_corr(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
 {
     using C = CorrCfg<NW, UB>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                                    // the attribute is per device
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    if (!attr_set[devid & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[devid & 63] = true;
     }
     const int UJ = 2 * dev.ms - 1, npass = UJ * ((UJ + UB - 1) / UB);
     const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
@@ -614,12 +616,14 @@ template <int KIND, int NW>
 inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& sep, hipStream_t s)
 {
     using C = PrepCfg<NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                                    // the attribute is per device
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    if (!attr_set[devid & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_maps_kernel<KIND, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[devid & 63] = true;
     }
     const int ntx = (M.W - 2 * NW + C::T - 1) / C::T, nty = (M.H - 2 * NW + C::T - 1) / C::T;
     const int total = ntx * nty, grid = ((total + 7) / 8) * 8;
