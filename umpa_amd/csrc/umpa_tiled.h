@@ -31,7 +31,6 @@ namespace umpa {
 
 #define UMPA_TILE 32
 #define UMPA_MAX_NW 8
-#define UMPA_CORR_THREADS 512
 #define UMPA_LDS_BUDGET (160 * 1024)
 
 struct Sep1D {                       // the two 1-D factors of the window, win[a][b] = hr[a]*hc[b]
@@ -197,26 +196,33 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
 // ------------------------------------------------------------------------------------------------
 // corr_volume
 // ------------------------------------------------------------------------------------------------
-template <int NW, int UB>
+// Tile = TR x TC output pixels (TR = 32 rows); NT threads; LDSB = LDS bytes one workgroup may use
+// (160 KiB / workgroups per CU).  Two shapes are built: 32x32 tiles with 512 threads, one workgroup per CU,
+// and 32x16 tiles with 256 threads, TWO workgroups per CU -- the two are independent, so while one waits for
+// its frames or drains its stores the other one computes (a single 8-wave workgroup runs its phases strictly
+// one after the other between barriers).
+template <int NW, int UB, int TC, int NT>
 struct CorrCfg {
-    static constexpr int T = UMPA_TILE, S = 2 * NW + 1, NT = UMPA_CORR_THREADS;
-    static constexpr int Q = T + 2 * NW;                  // q-region edge (tile + window halo)
-    static constexpr int QP = Q | 1;                      // odd row stride of the transposed tiles
-    static constexpr int NQB = NT / Q;                    // q column-blocks handled side by side
-    static constexpr int QB = (Q + NQB - 1) / NQB;        // q columns per thread
-    static constexpr int AC = NQB * QB;                   // columns the product threads address (>= Q; the excess is never stored)
-    static constexpr int BW = Q + UB - 1;                 // B columns staged
-    static constexpr int AFR = Q * QP, BFR = BW * QP;     // doubles per staged frame: packed, A then B
+    static constexpr int TR = UMPA_TILE, S = 2 * NW + 1;
+    static constexpr int LDSB = (NT >= 512) ? UMPA_LDS_BUDGET : UMPA_LDS_BUDGET / 2;
+    static constexpr int QR = TR + 2 * NW, QC = TC + 2 * NW;  // q-region (tile + window halo): rows, columns
+    static constexpr int QP = QR | 1;                     // odd pitch of the transposed tiles ([column][row])
+    static constexpr int NQB = NT / QR;                   // q column-blocks handled side by side
+    static constexpr int QB = (QC + NQB - 1) / NQB;       // q columns per thread
+    static constexpr int AC = NQB * QB;                   // columns the product threads address (>= QC; the excess is never stored)
+    static constexpr int BW = QC + UB - 1;                // B columns staged
+    static constexpr int AFR = QC * QP, BFR = BW * QP;    // doubles per staged frame: packed, A then B
     static constexpr int FRAME = AFR + BFR;
-    static constexpr int SLACK = (AC - Q) * QP;           // threads of the padding columns read this far past a frame
-    static constexpr int PPL = Q * QP;                    // one product plane
-    static constexpr int FCH = (UMPA_LDS_BUDGET / 8 - SLACK) / FRAME;   // frames staged per barrier
+    static constexpr int SLACK = (AC - QC) * QP;          // threads of the padding columns read this far past a frame
+    static constexpr int PPL = QC * QP;                   // one product plane
+    static constexpr int FCH_FIT = (LDSB / 8 - SLACK) / FRAME;
+    static constexpr int FCH = FCH_FIT > 5 ? 5 : FCH_FIT; // frames staged per barrier (each costs prefetch registers)
     static constexpr int LDS_DOUBLES = (FCH * FRAME + SLACK > UB * PPL) ? FCH * FRAME + SLACK : UB * PPL;
     static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
     static constexpr int CB = 8;                          // outputs per filter item
-    static constexpr int HITEMS = UB * (T / CB) * Q, HROUNDS = (HITEMS + NT - 1) / NT;
-    static constexpr int VITEMS = UB * (T / CB) * T, VROUNDS = (VITEMS + NT - 1) / NT;
-    static constexpr bool OK = FCH >= 1 && UB * PPL * 8 <= UMPA_LDS_BUDGET;   // frames and product planes fit into LDS
+    static constexpr int HITEMS = UB * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
+    static constexpr int VITEMS = UB * (TR / CB) * TC, VROUNDS = (VITEMS + NT - 1) / NT;
+    static constexpr bool OK = FCH_FIT >= 1 && UB * PPL * 8 <= LDSB && NQB >= 1;   // frames and product planes fit into LDS
 };
 
 struct CorrArgs {
@@ -230,11 +236,11 @@ struct CorrArgs {
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE): 1 no global loads, 2 no LDS staging writes, 4 no products, 8 no filters
 };
 
-template <int NW, int UB>
-__global__ void __launch_bounds__(UMPA_CORR_THREADS)
+template <int NW, int UB, int TC, int NT>
+__global__ void __launch_bounds__(NT, 2)
 corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
 {
-    using C = CorrCfg<NW, UB>;
+    using C = CorrCfg<NW, UB, TC, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
 
@@ -251,35 +257,30 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
     if (seq / npass >= tiles_per_xcd || lin >= ntiles) return;
     const int tx = lin % A.ntx, ty = lin / A.ntx;
     const int tid = threadIdx.x;
-    const int prow0 = A.row0 + ty * C::T, pcol0 = tx * C::T;          // first output pixel of the tile (region coords)
+    const int prow0 = A.row0 + ty * C::TR, pcol0 = tx * TC;           // first output pixel of the tile (region coords)
     const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
     const int H = gp(m.frames)->H, W = gp(m.frames)->W;
     const int oi = pass / nbatch - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
 
     // ---- staging slots of this thread (compile-time counts, so everything below indexes registers statically)
-    constexpr int NA = (C::Q * C::Q + C::NT - 1) / C::NT;             // A elements per thread and frame
-    constexpr int NB = (C::Q * C::BW + C::NT - 1) / C::NT;            // B elements per thread and frame
-    int a_lds[NA], a_g[NA], b_lds[NB], b_r[NB], b_c[NB], b_g[NB];
+    constexpr int NA = (C::QR * C::QC + NT - 1) / NT;                 // A elements per thread and frame
+    constexpr int NB = (C::QR * C::BW + NT - 1) / NT;                 // B elements per thread and frame
+    int a_lds[NA], a_g[NA], b_lds[NB], b_g[NB];
 #pragma unroll
     for (int n = 0; n < NA; n++) {
-        const int it = tid + n * C::NT, c = it % C::Q, r = it / C::Q;
-        a_lds[n] = it < C::Q * C::Q ? c * C::QP + r : -1;
+        const int it = tid + n * NT, c = it % C::QC, r = it / C::QC;
+        a_lds[n] = it < C::QR * C::QC ? c * C::QP + r : -1;
         a_g[n] = min(max(fr0 + r, 0), H - 1) * W + min(max(fc0 + c, 0), W - 1);
     }
 #pragma unroll
     for (int n = 0; n < NB; n++) {
-        const int it = tid + n * C::NT, c = it % C::BW, r = it / C::BW;
-        b_lds[n] = it < C::Q * C::BW ? c * C::QP + r : -1;
-        b_r[n] = fr0 + r;
-        b_c[n] = fc0 + c;
+        const int it = tid + n * NT, c = it % C::BW, r = it / C::BW;
+        b_lds[n] = it < C::QR * C::BW ? c * C::QP + r : -1;
+        b_g[n] = min(max(fr0 + r + oi, 0), H - 1) * W + min(max(fc0 + c + oj0, 0), W - 1);
     }
     double pa[C::FCH][NA], pb[C::FCH][NB];                            // frames in flight from HBM/L2
 
     const int nchunk = (m.Na + C::FCH - 1) / C::FCH;
-#pragma unroll
-    for (int n = 0; n < NB; n++)
-        b_g[n] = min(max(b_r[n] + oi, 0), H - 1) * W + min(max(b_c[n] + oj0, 0), W - 1);
-
     auto issue_loads = [&](int chunk) {
         const int k0 = chunk * C::FCH;
 #pragma unroll
@@ -304,7 +305,7 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
     };
 
     // product-stage ownership: (qb, r), r fastest
-    const int pr = tid % C::Q, pqb = tid / C::Q;
+    const int pr = tid % C::QR, pqb = tid / C::QR;
     const bool pactive = pqb < C::NQB;
     double acc[C::QB][UB];
 
@@ -355,7 +356,7 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
 #pragma unroll
             for (int t = 0; t < C::QB; t++) {
                 const int c = pqb * C::QB + t;
-                if (c < C::Q) {
+                if (c < C::QC) {
 #pragma unroll
                     for (int u = 0; u < UB; u++) lds[u * C::PPL + c * C::QP + pr] = acc[t][u];
                 }
@@ -366,18 +367,18 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         double hres[C::HROUNDS][C::CB];
 #pragma unroll
         for (int rd = 0; rd < C::HROUNDS; rd++) {
-            const int it = tid + rd * C::NT;
+            const int it = tid + rd * NT;
             if (it < C::HITEMS) {
-                const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
                 fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int rd = 0; rd < C::HROUNDS; rd++) {
-            const int it = tid + rd * C::NT;
+            const int it = tid + rd * NT;
             if (it < C::HITEMS) {
-                const int r = it % C::Q, rest = it / C::Q, cb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
                 double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
 #pragma unroll
                 for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
@@ -387,9 +388,9 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         // V stage (along rows) and store: items (u, rb, c), c fastest -> coalesced table rows
 #pragma unroll
         for (int rd = 0; rd < C::VROUNDS; rd++) {
-            const int it = tid + rd * C::NT;
+            const int it = tid + rd * NT;
             if (it < C::VITEMS) {
-                const int c = it % C::T, rest = it / C::T, rb = rest % (C::T / C::CB), u = rest / (C::T / C::CB);
+                const int c = it % TC, rest = it / TC, rb = rest % (C::TR / C::CB), u = rest / (C::TR / C::CB);
                 if (u < nu) {
                     double out[C::CB];
                     fir_block<NW, C::CB>(lds + u * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
@@ -573,43 +574,61 @@ inline int pick_ub(int UJ)
     return best;
 }
 
-template <int NW, int UB>
-inline hipError_t launch_corr(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
+inline int tiled_tile_cols()
 {
-    using C = CorrCfg<NW, UB>;
+    const char* e = getenv("UMPA_HIP_TILE_COLS");                     // 16 or 32; default: 16 where it fits
+    return e ? atoi(e) : 16;
+}
+
+template <int NW, int UB, int TC, int NT>
+inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep, hipStream_t s)
+{
+    using C = CorrCfg<NW, UB, TC, NT>;
     static bool attr_set[64] = {};                                    // the attribute is per device
     int devid = 0;
     (void)hipGetDevice(&devid);
     if (!attr_set[devid & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB, TC, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         if (e != hipSuccess) return e;
         attr_set[devid & 63] = true;
     }
+    A.ntx = (A.N1 + TC - 1) / TC;
+    A.nty = (A.rows + C::TR - 1) / C::TR;
     const int UJ = 2 * dev.ms - 1, npass = UJ * ((UJ + UB - 1) / UB);
     const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
     const int grid = 8 * tiles_per_xcd * npass;
-    hipLaunchKernelGGL((corr_volume_kernel<NW, UB>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
+    hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NT>), dim3(grid), dim3(NT), C::LDS, s, dev, A, sep);
     return hipGetLastError();
+}
+
+// 32x16 tiles / 256 threads / two workgroups per CU where the product planes fit into half the LDS, else 32x32 / 512
+template <int NW, int UB>
+inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
+{
+    if constexpr (CorrCfg<NW, UB, 16, 256>::OK) {
+        if (tiled_tile_cols() == 16) return launch_corr<NW, UB, 16, 256>(dev, A, sep, s);
+    }
+    return launch_corr<NW, UB, 32, 512>(dev, A, sep, s);
 }
 
 template <int NW>
 inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
 {
     if (ub == 9) {
-        if constexpr (CorrCfg<NW, 9>::OK) return launch_corr<NW, 9>(dev, A, sep, s);
+        if constexpr (CorrCfg<NW, 9, 32, 512>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s);
         ub = 8;
     }
     if (ub == 8) {
-        if constexpr (CorrCfg<NW, 8>::OK) return launch_corr<NW, 8>(dev, A, sep, s);
+        if constexpr (CorrCfg<NW, 8, 32, 512>::OK) return launch_corr_shape<NW, 8>(dev, A, sep, s);
         ub = 7;
     }
     if (ub == 7) {
-        if constexpr (CorrCfg<NW, 7>::OK) return launch_corr<NW, 7>(dev, A, sep, s);
+        if constexpr (CorrCfg<NW, 7, 32, 512>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s);
         ub = 5;
     }
-    static_assert(CorrCfg<NW, 5>::OK, "UB=5 must always fit");
-    return launch_corr<NW, 5>(dev, A, sep, s);
+    static_assert(CorrCfg<NW, 5, 32, 512>::OK, "UB=5 must always fit");
+    return launch_corr_shape<NW, 5>(dev, A, sep, s);
 }
 
 template <int KIND, int NW>
@@ -706,7 +725,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = row0; CA.rows = rows; CA.N1 = A.N1;
         CA.sigma = dev.ref_mode ? -1 : 1;
         { const char* ab = getenv("UMPA_HIP_ABLATE"); CA.ablate = ab ? atoi(ab) : 0; }
-        CA.ntx = (A.N1 + UMPA_TILE - 1) / UMPA_TILE; CA.nty = (rows + UMPA_TILE - 1) / UMPA_TILE;
+        CA.ntx = CA.nty = 0;                                          // set by launch_corr for the tile shape it picks
         e = hipErrorInvalidValue;
         tic(3);
         UMPA_NW_SWITCH(Nw, (e = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s)))
