@@ -262,23 +262,27 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
     const int H = gp(m.frames)->H, W = gp(m.frames)->W;
     const int oi = pass / nbatch - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
 
-    // ---- staging slots of this thread (compile-time counts, so everything below indexes registers statically)
-    constexpr int NA = (C::QR * C::QC + NT - 1) / NT;                 // A elements per thread and frame
-    constexpr int NB = (C::QR * C::BW + NT - 1) / NT;                 // B elements per thread and frame
+    // ---- staging slots of this thread (compile-time counts, so everything below indexes registers statically).
+    // An element is EW adjacent columns of one row: with even patch widths two doubles travel per load
+    // (global_load_dwordx4: the L1/TA path moves 16 bytes per lane at about twice the rate of 8-byte loads).
+    constexpr int EW = (C::QC % 2 == 0 && C::BW % 2 == 0) ? 2 : 1;
+    typedef double stage_t __attribute__((ext_vector_type(EW), aligned(8)));
+    constexpr int NA = (C::QR * C::QC / EW + NT - 1) / NT;            // A elements per thread and frame
+    constexpr int NB = (C::QR * C::BW / EW + NT - 1) / NT;            // B elements per thread and frame
     int a_lds[NA], a_g[NA], b_lds[NB], b_g[NB];
 #pragma unroll
     for (int n = 0; n < NA; n++) {
-        const int it = tid + n * NT, c = it % C::QC, r = it / C::QC;
-        a_lds[n] = it < C::QR * C::QC ? c * C::QP + r : -1;
-        a_g[n] = min(max(fr0 + r, 0), H - 1) * W + min(max(fc0 + c, 0), W - 1);
+        const int it = tid + n * NT, c = (it % (C::QC / EW)) * EW, r = it / (C::QC / EW);
+        a_lds[n] = it < C::QR * C::QC / EW ? c * C::QP + r : -1;
+        a_g[n] = min(max(fr0 + r, 0), H - 1) * W + min(max(fc0 + c, 0), W - EW);
     }
 #pragma unroll
     for (int n = 0; n < NB; n++) {
-        const int it = tid + n * NT, c = it % C::BW, r = it / C::BW;
-        b_lds[n] = it < C::QR * C::BW ? c * C::QP + r : -1;
-        b_g[n] = min(max(fr0 + r + oi, 0), H - 1) * W + min(max(fc0 + c + oj0, 0), W - 1);
+        const int it = tid + n * NT, c = (it % (C::BW / EW)) * EW, r = it / (C::BW / EW);
+        b_lds[n] = it < C::QR * C::BW / EW ? c * C::QP + r : -1;
+        b_g[n] = min(max(fr0 + r + oi, 0), H - 1) * W + min(max(fc0 + c + oj0, 0), W - EW);
     }
-    double pa[C::FCH][NA], pb[C::FCH][NB];                            // frames in flight from HBM/L2
+    stage_t pa[C::FCH][NA], pb[C::FCH][NB];                           // frames in flight from HBM/L2
 
     const int nchunk = (m.Na + C::FCH - 1) / C::FCH;
     auto issue_loads = [&](int chunk) {
@@ -291,14 +295,14 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
                 const UMPA_GLOBAL double* __restrict__ gB = gp(A.sigma > 0 ? fd.ref : fd.sam);
                 if (A.ablate & 1) {
 #pragma unroll
-                    for (int n = 0; n < NA; n++) pa[f][n] = 1.0;
+                    for (int n = 0; n < NA; n++) pa[f][n] = (stage_t)(1.0);
 #pragma unroll
-                    for (int n = 0; n < NB; n++) pb[f][n] = 1.0;
+                    for (int n = 0; n < NB; n++) pb[f][n] = (stage_t)(1.0);
                 } else {
 #pragma unroll
-                    for (int n = 0; n < NA; n++) pa[f][n] = gA[a_g[n]];
+                    for (int n = 0; n < NA; n++) pa[f][n] = *reinterpret_cast<const UMPA_GLOBAL stage_t*>(gA + a_g[n]);
 #pragma unroll
-                    for (int n = 0; n < NB; n++) pb[f][n] = gB[b_g[n]];
+                    for (int n = 0; n < NB; n++) pb[f][n] = *reinterpret_cast<const UMPA_GLOBAL stage_t*>(gB + b_g[n]);
                 }
             }
         }
@@ -324,9 +328,17 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
                 double* la = lds + f * C::FRAME;
                 double* lb = la + C::AFR;
 #pragma unroll
-                for (int n = 0; n < NA; n++) if (a_lds[n] >= 0) la[a_lds[n]] = pa[f][n];
+                for (int n = 0; n < NA; n++)
+                    if (a_lds[n] >= 0) {
 #pragma unroll
-                for (int n = 0; n < NB; n++) if (b_lds[n] >= 0) lb[b_lds[n]] = pb[f][n];
+                        for (int e = 0; e < EW; e++) la[a_lds[n] + e * C::QP] = EW == 2 ? pa[f][n][e] : ((const double*)&pa[f][n])[0];
+                    }
+#pragma unroll
+                for (int n = 0; n < NB; n++)
+                    if (b_lds[n] >= 0) {
+#pragma unroll
+                        for (int e = 0; e < EW; e++) lb[b_lds[n] + e * C::QP] = EW == 2 ? pb[f][n][e] : ((const double*)&pb[f][n])[0];
+                    }
             }
         }
         if (chunk + 1 < nchunk) issue_loads(chunk + 1);               // flies while this chunk is consumed
