@@ -95,6 +95,8 @@ def test_dfkernel_single_pixel_and_mask(hip_ns, port_ns):
     dict(H=130, W=150, K=8, Nw=6, ms=7, df=True, amp=4.5),
     dict(H=90, W=90, K=1, Nw=1, ms=4, df=True, amp=2.0),
     dict(H=64, W=80, K=2, Nw=0, ms=4, df=False, amp=2.0),
+    dict(H=77, W=91, K=3, Nw=3, ms=4, df=True, amp=2.0),       # odd output width: unaligned table rows in the tiled path
+    dict(H=101, W=67, K=2, Nw=6, ms=3, df=False, amp=0.3),     # 32x32-tile shape of the tiled path (Nw > 5), small search range
 ])
 def test_hip_matches_oracle_on_seeded_inputs(hip_ns, port_ns, cfg):
     from umpa_amd.synth import make_stack
