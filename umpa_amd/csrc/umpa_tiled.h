@@ -744,7 +744,8 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     toc();
     if (e != hipSuccess) return (int)e;
 
-    const int ub = pick_ub(UJ);
+    int ub = pick_ub(UJ);
+    { const char* e = getenv("UMPA_HIP_UB"); if (e) ub = atoi(e); }      // tuning override: 9, 8, 7 or 5
     for (int row0 = 0; row0 < A.N0; row0 += (int)rows_chunk) {
         const int rows = (int)((A.N0 - row0 < rows_chunk) ? A.N0 - row0 : rows_chunk);
         CorrArgs CA;
