@@ -504,10 +504,8 @@ __global__ void __launch_bounds__(UMPA_WALK_THREADS, 3)
 replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
 {
     __shared__ double memo_lds[25 * UMPA_WALK_THREADS];
-    // a wave covers a compact 4 x 16 pixel patch (128-byte row segments): neighbouring pixels walk alike, so
-    // the lanes of a wave diverge less and finish closer together than along a 64-pixel strip
-    const int xj = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int xi = R.row0 + blockIdx.y * 16 + threadIdx.y * 4 + (threadIdx.x >> 4);
+    const int xj = blockIdx.x * 64 + threadIdx.x;
+    const int xi = R.row0 + blockIdx.y * 4 + threadIdx.y;
     if (xi >= R.row0 + R.rows || xj >= A.N1) return;
     const size_t px = (size_t)xi * A.N1 + xj;
     const size_t tpx = (size_t)(xi - R.row0) * A.N1 + xj;
@@ -765,7 +763,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         ReplayArgs R;
         R.table = st.table; R.slot_stride = CA.slot_stride; R.row0 = row0; R.rows = rows;
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
-        dim3 blk(64, 4), grd((A.N1 + 15) / 16, (rows + 15) / 16);
+        dim3 blk(64, 4), grd((A.N1 + 63) / 64, (rows + 3) / 4);
         tic(4);
         if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1>), grd, blk, 0, s, dev, M, R, A);
         else hipLaunchKernelGGL((replay_walk_kernel<0>), grd, blk, 0, s, dev, M, R, A);
