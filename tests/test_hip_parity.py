@@ -218,3 +218,16 @@ def test_update_frames_and_projection_farm(hip_ns):
     for p in range(3):
         for k in ("f", "T", "dx", "dy", "df", "err"):
             np.testing.assert_array_equal(res[p][k], want[p][k])
+
+
+def test_plain_c_host_of_the_c_abi(hip_ns, tmp_path):
+    """examples/c_host.c: the boundary is a C ABI -- a host with no Python and no PyTorch in the process."""
+    import subprocess
+    from conftest import REPO
+    exe = str(tmp_path / "c_host")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "examples", "c_host.c"),
+                    "-o", exe, "-L" + os.path.join(REPO, "umpa_amd"), "-lumpa_hip",
+                    "-Wl,-rpath," + os.path.join(REPO, "umpa_amd"), "-lm"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "path = 2" in out.stdout                    # the tiled fast path served it
