@@ -130,25 +130,44 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
         const UMPA_GLOBAL double* __restrict__ MQ = MASK ? gp(f.mask) + qo : nullptr;
 
         double s2 = 0, s4 = 0, s6 = 0, sm = 0;
+        // one window element: the arithmetic and the order of Model.cpp:746-772 (and :813-841 with masks)
+        auto term = [&](double w, double r, double q, double mr, double mq) {
+            if (MASK) {
+                if (KIND == 1) sm += w * r;              // the ref mean is never mask-weighted (Model.cpp:804)
+                w *= pair_weight(mr, mq);
+                wt += w;
+                s2 += w;
+            }
+            const double wq = w * q, wr = w * r;
+            t1 += wq * q;
+            t3 += wr * r;
+            t5 += wr * q;
+            if (KIND == 1) { s4 += wq; s6 += wr; }
+        };
+        typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
         for (int a = 0; a < S; a++) {
             const UMPA_GLOBAL double* wrow = gp(m.win) + a * S;
             const size_t off = (size_t)a * f.W;
-            for (int b = 0; b < S; b++) {
-                double w = wrow[b];
+            int b = 0;
+            if (KIND != 2) {
+                // two columns per step: 16-byte loads (the L1/TA path is half-rate for 8-byte ones); the terms are
+                // still accumulated in the reference's order
+                for (; b + 1 < S; b += 2) {
+                    const pair_t r2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(R + off + b);
+                    const pair_t q2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(Q + off + b);
+                    pair_t mr2 = {0.0, 0.0}, mq2 = {0.0, 0.0};
+                    if (MASK) {
+                        mr2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(MR + off + b);
+                        mq2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(MQ + off + b);
+                    }
+                    term(wrow[b], r2[0], q2[0], mr2[0], mq2[0]);
+                    term(wrow[b + 1], r2[1], q2[1], mr2[1], mq2[1]);
+                }
+            }
+            for (; b < S; b++) {
                 const double r = KIND == 2 ? blur_at<MASK>(gp(f.ref), gp(f.mask), f.W, ri - f.pi - Nw + a, rj - f.pj - Nw + b, kern, kstride)
                                            : R[off + b];
-                const double q = Q[off + b];
-                if (MASK) {
-                    if (KIND == 1) sm += w * r;          // the ref mean is never mask-weighted (Model.cpp:804)
-                    w *= pair_weight(MR[off + b], MQ[off + b]);
-                    wt += w;
-                    s2 += w;
-                }
-                const double wq = w * q, wr = w * r;
-                t1 += wq * q;
-                t3 += wr * r;
-                t5 += wr * q;
-                if (KIND == 1) { s4 += wq; s6 += wr; }
+                term(wrow[b], r, Q[off + b], MASK ? MR[off + b] : 0.0, MASK ? MQ[off + b] : 0.0);
             }
         }
         if (KIND == 1) {                                 // Model.cpp:739,:770-772 / :808,:843-845
