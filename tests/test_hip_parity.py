@@ -163,6 +163,11 @@ def test_api_conventions(hip_ns):
     assert r['f'].shape == ((m.extent[0] + 1) // 2, (m.extent[1] + 1) // 2)
     r2 = umpa_amd.match(case.sam, case.ref, 2, step=2, df=False)
     assert 'df' not in r2
+    rb = umpa_amd.match_unbiased(case.sam, case.ref, 2, step=2)          # shares the resident reference stack
+    rr = umpa_amd.match(case.ref, case.ref, 2, step=2)
+    np.testing.assert_array_equal(rb['dx'], r['dx'] - rr['dx'])
+    np.testing.assert_array_equal(rb['dy'], r['dy'] - rr['dy'])
+    np.testing.assert_array_equal(rb['T'], r['T'])
     ru = umpa_amd.match_unbiased(case.sam, case.ref, 2, step=2, bias=(0.25, -0.5))
     np.testing.assert_allclose(ru['dx'], r['dx'] - 0.25)
     np.testing.assert_allclose(ru['dy'], r['dy'] + 0.5)

@@ -41,10 +41,21 @@ def match_unbiased(Isample, Iref, Nw, mask=None, step=1, max_shift=4, df=True, b
     """
     if bias is True:
         cls = model.UMPAModelDF if df else model.UMPAModelNoDF
+        Isample = _contiguous(Isample, 'sample')
+        Iref = _contiguous(Iref, 'reference')
         PMref = cls(sam_list=Iref, ref_list=Iref, mask_list=mask, window_size=Nw)
         bias_result = PMref.match(step=step)
         dx = bias_result['dx']
         dy = bias_result['dy']
+        if PMref._lib.is_hip and not hasattr(PMref._sam[0], "data_ptr"):
+            # both matches share the reference stack: keep it resident on the GPU and swap only the sample stack
+            # (same numbers as building a second model, which is what the reference does)
+            PMref.update_frames(sam_list=Isample)
+            PMref.ROI = None
+            result = PMref.match(step=step)
+            result['dx'] -= dx
+            result['dy'] -= dy
+            return result
     elif bias is False:
         dx = 0.
         dy = 0.
