@@ -96,7 +96,9 @@ def test_dfkernel_single_pixel_and_mask(hip_ns, port_ns):
     dict(H=90, W=90, K=1, Nw=1, ms=4, df=True, amp=2.0),
     dict(H=64, W=80, K=2, Nw=0, ms=4, df=False, amp=2.0),
     dict(H=77, W=91, K=3, Nw=3, ms=4, df=True, amp=2.0),       # odd output width: unaligned table rows in the tiled path
-    dict(H=101, W=67, K=2, Nw=6, ms=3, df=False, amp=0.3),     # 32x32-tile shape of the tiled path (Nw > 5), small search range
+    dict(H=101, W=67, K=2, Nw=6, ms=3, df=False, amp=0.3),
+    dict(H=120, W=131, K=3, Nw=8, ms=5, df=True, amp=2.0),      # widest window the tiled path is built for
+    dict(H=70, W=75, K=18, Nw=2, ms=4, df=True, amp=1.5),       # more frames than replay_walk keeps in registers     # 32x32-tile shape of the tiled path (Nw > 5), small search range
 ])
 def test_hip_matches_oracle_on_seeded_inputs(hip_ns, port_ns, cfg):
     from umpa_amd.synth import make_stack
