@@ -238,3 +238,30 @@ def test_plain_c_host_of_the_c_abi(hip_ns, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "path = 2" in out.stdout                    # the tiled fast path served it
+
+
+def test_stepped_and_chunked_tiled_path_matches_direct(hip_ns, monkeypatch):
+    """Small steps run on the tiled path over the dense grid; a tiny table budget forces several row chunks."""
+    from umpa_amd import _lib
+    from umpa_amd.synth import make_stack
+    monkeypatch.setenv("UMPA_HIP_TABLE_MB", "16")
+    sam, ref, _ = make_stack(400, 300, 4, 4, df=True, seed=77, amplitude=1.5, order=1)
+    res = {}
+    for force in ("tiled", "direct"):
+        m = hip_ns.UMPAModelDF(sam, ref, window_size=3, max_shift=4)
+        m.debug = "ncalls"
+        m._force = _lib.F_FORCE_TILED if force == "tiled" else _lib.F_FORCE_DIRECT
+        res[force] = [m.match(ROI=((3, 380, 2), (5, 280, 3)), quiet=True), m.match(step=3, quiet=True),
+                      m.match(ROI=((0, 386, 1), (0, 286, 1)), quiet=True)]
+        assert m._lib.last_path(m._handle) == (2 if force == "tiled" else 1)
+    for a, b in zip(res["tiled"], res["direct"]):
+        np.testing.assert_array_equal(a["err"], b["err"])
+        np.testing.assert_array_equal(a["debug_Ncalls"], b["debug_Ncalls"])
+        ok = b["err"] == 1
+        np.testing.assert_allclose(a["T"][ok], b["T"][ok], rtol=1e-9)
+        np.testing.assert_allclose(a["df"][ok], b["df"][ok], rtol=1e-9)
+        assert np.mean(np.abs(a["dx"] - b["dx"])[ok] > 1e-6) < 2e-3
+    with pytest.raises(_lib.NativeError, match="does not cover"):
+        m = hip_ns.UMPAModelDF(sam, ref, window_size=3, max_shift=4)
+        m._force = _lib.F_FORCE_TILED
+        m.match(step=4, quiet=True)                       # 16 dense pixels per output pixel: left to the direct kernel

@@ -210,7 +210,9 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
         if (m->pos[2 * k] || m->pos[2 * k + 1]) return false;
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
     }
-    if (A.step0 != 1 || A.step1 != 1) return false;
+    // stepped regions: the tiled kernels still compute the dense grid, which pays while step0*step1 is small
+    // (the direct kernel's cost is per requested pixel, about 20x the tiled cost per dense pixel)
+    if (A.step0 * A.step1 > 9) return false;
     // the region must keep every window inside the frames even for the partial tiles' halo reads: guaranteed
     // by check_region + clamped staging.  Separable window required (always true for the Hamming window).
     if (!m->tiled.separable || m->tiled.sep_nw != m->Nw) return false;

@@ -440,9 +440,10 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
 // replay_walk
 // ------------------------------------------------------------------------------------------------
 struct ReplayArgs {
-    const double* table;
-    size_t slot_stride;
-    int row0, rows;           // region rows covered by the table
+    const double* table;      // [(2ms-1)^2][drows][N1d]: the DENSE (unit-step) grid under the requested region
+    size_t slot_stride;       // drows * N1d
+    int drow0, N1d;           // first dense row held by the table, dense row length
+    int row0, rows;           // OUTPUT rows [row0, row0+rows) whose dense rows the table holds
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE_REPLAY): 1 = 18 fixed lookups instead of the walk, 2 = no sub-pixel fit
 };
 
@@ -508,9 +509,9 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
     const int xi = R.row0 + blockIdx.y * 4 + threadIdx.y;
     if (xi >= R.row0 + R.rows || xj >= A.N1) return;
     const size_t px = (size_t)xi * A.N1 + xj;
-    const size_t tpx = (size_t)(xi - R.row0) * A.N1 + xj;
+    const size_t tpx = (size_t)(xi * A.step0 - R.drow0) * R.N1d + (size_t)xj * A.step1;
     if (A.cover && gp(A.cover)[px] < A.thr) return;
-    const int i = A.org0 + xi, j = A.org1 + xj;
+    const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
     double fixed[UMPA_KFIX];
     if (KIND == 1) {
         const size_t plane = (size_t)M.H * M.W;
@@ -721,12 +722,15 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     M.WS = kind == 1 ? st.maps + 4 * plane : nullptr;
     M.MR = kind == 1 ? st.maps + (4 + (size_t)K) * plane : nullptr;
 
-    // rows per chunk: the shift table of one chunk stays within the budget (whole tiles)
-    const size_t row_bytes = (size_t)UJ * UJ * A.N1 * sizeof(double);
+    // The table lives on the dense (unit-step) grid under the region: with step > 1 every step-th entry is used
+    // (tiled_applicable only sends small steps here).  Rows per chunk: the shift table of one chunk stays within
+    // the budget (whole tiles).
+    const int N0d = A.step0 * (A.N0 - 1) + 1, N1d = A.step1 * (A.N1 - 1) + 1;
+    const size_t row_bytes = (size_t)UJ * UJ * N1d * sizeof(double);
     long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
     if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
-    if (rows_chunk > A.N0) rows_chunk = ((long)A.N0 + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
-    const size_t table_need = (size_t)UJ * UJ * rows_chunk * A.N1;
+    if (rows_chunk > N0d) rows_chunk = ((long)N0d + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+    const size_t table_need = (size_t)UJ * UJ * rows_chunk * N1d;
     if (st.table_cap < table_need) {
         if (st.table) (void)hipFree(st.table);
         st.table = nullptr; st.table_cap = 0;
@@ -746,11 +750,11 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
 
     int ub = pick_ub(UJ);
     { const char* e = getenv("UMPA_HIP_UB"); if (e) ub = atoi(e); }      // tuning override: 9, 8, 7 or 5
-    for (int row0 = 0; row0 < A.N0; row0 += (int)rows_chunk) {
-        const int rows = (int)((A.N0 - row0 < rows_chunk) ? A.N0 - row0 : rows_chunk);
+    for (int drow0 = 0; drow0 < N0d; drow0 += (int)rows_chunk) {
+        const int drows = (int)((N0d - drow0 < rows_chunk) ? N0d - drow0 : rows_chunk);
         CorrArgs CA;
-        CA.table = st.table; CA.slot_stride = (size_t)rows * A.N1;
-        CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = row0; CA.rows = rows; CA.N1 = A.N1;
+        CA.table = st.table; CA.slot_stride = (size_t)drows * N1d;
+        CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = drow0; CA.rows = drows; CA.N1 = N1d;
         CA.sigma = dev.ref_mode ? -1 : 1;
         { const char* ab = getenv("UMPA_HIP_ABLATE"); CA.ablate = ab ? atoi(ab) : 0; }
         CA.ntx = CA.nty = 0;                                          // set by launch_corr for the tile shape it picks
@@ -760,10 +764,15 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         toc();
         if (e != hipSuccess) return (int)e;
 
+        // output rows whose dense row lies in [drow0, drow0 + drows)
+        const int xi_lo = (drow0 + A.step0 - 1) / A.step0;
+        const int xi_hi = std::min(A.N0, (drow0 + drows - 1) / A.step0 + 1);
+        if (xi_hi <= xi_lo) continue;
         ReplayArgs R;
-        R.table = st.table; R.slot_stride = CA.slot_stride; R.row0 = row0; R.rows = rows;
+        R.table = st.table; R.slot_stride = CA.slot_stride; R.drow0 = drow0; R.N1d = N1d;
+        R.row0 = xi_lo; R.rows = xi_hi - xi_lo;
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
-        dim3 blk(64, 4), grd((A.N1 + 63) / 64, (rows + 3) / 4);
+        dim3 blk(64, 4), grd((A.N1 + 63) / 64, (R.rows + 3) / 4);
         tic(4);
         if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1>), grd, blk, 0, s, dev, M, R, A);
         else hipLaunchKernelGGL((replay_walk_kernel<0>), grd, blk, 0, s, dev, M, R, A);
