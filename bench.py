@@ -60,13 +60,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL ("nccl"); UMPA_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal
+    backend = os.environ.get("UMPA_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1 and args.gpus == 1, \
         "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll = dev if backend == "nccl" else torch.device("cpu")        # where the timing all-reduce lives
 
     cfg = dict(CONFIGS[args.config])
     if args.rows:
@@ -111,7 +118,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     lib.timing_enable(h, 0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
