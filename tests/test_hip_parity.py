@@ -265,3 +265,21 @@ def test_stepped_and_chunked_tiled_path_matches_direct(hip_ns, monkeypatch):
         m = hip_ns.UMPAModelDF(sam, ref, window_size=3, max_shift=4)
         m._force = _lib.F_FORCE_TILED
         m.match(step=4, quiet=True)                       # 16 dense pixels per output pixel: left to the direct kernel
+
+
+def test_degenerate_sizes_on_device(hip_ns, port_ns):
+    """One-pixel and one-row outputs, constant frames (zero-variance windows): same answers as the oracle."""
+    from umpa_amd.synth import make_stack
+    sam, ref, _ = make_stack(13, 13, 2, 4, df=True, seed=1, amplitude=0.5)
+    for name in ("UMPAModelDF", "UMPAModelNoDF"):
+        g = getattr(hip_ns, name)(sam, ref, window_size=2, max_shift=4).match(quiet=True)
+        o = getattr(port_ns, name)(sam, ref, window_size=2, max_shift=4).match(quiet=True)
+        assert g["f"].shape == (1, 1)
+        np.testing.assert_array_equal(g["err"], o["err"])
+        np.testing.assert_array_equal(g["debug_Ncalls"], o["debug_Ncalls"])
+    sam, ref, _ = make_stack(15, 90, 3, 4, df=True, seed=2, amplitude=0.5)       # 3 output rows
+    g = hip_ns.UMPAModelDF(sam, ref, window_size=2, max_shift=4).match(quiet=True)
+    o = port_ns.UMPAModelDF(sam, ref, window_size=2, max_shift=4).match(quiet=True)
+    assert_parity(g, o, 4, "3-row output")
+    with pytest.raises(RuntimeError, match="Empty ROI"):
+        hip_ns.UMPAModelDF(np.ones((2, 12, 30)), np.ones((2, 12, 30)), window_size=2, max_shift=4).match(quiet=True)

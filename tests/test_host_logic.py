@@ -100,3 +100,17 @@ def test_match_unbiased_and_list_inputs(port_ns, case, monkeypatch):
     np.testing.assert_allclose(ru["dy"], r["dy"] - rr["dy"])
     rn = speckle_matching.match_unbiased(frames, refs, 2, step=2, df=False, bias=False)
     assert "df" not in rn
+
+
+def test_degenerate_sizes(port_ns):
+    """Frames no larger than twice the padding leave nothing to reconstruct: a clean error, not a crash."""
+    a = np.ones((2, 12, 30))
+    m = port_ns.UMPAModelDF(a, a, window_size=2, max_shift=4)           # padding 6: extent (0, 18)
+    assert m.extent == (0, 18)
+    with pytest.raises(RuntimeError, match="Empty ROI"):
+        m.match(quiet=True)
+    b = np.ones((1, 13, 13))
+    m = port_ns.UMPAModelNoDF(b, b, window_size=2, max_shift=4)         # exactly one output pixel
+    assert m.extent == (1, 1)
+    r = m.match(quiet=True)
+    assert r["f"].shape == (1, 1) and r["err"].dtype == np.int32
