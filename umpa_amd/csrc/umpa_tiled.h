@@ -452,7 +452,16 @@ struct ReplayArgs {
 // One "cost evaluation" of the walk: table lookup + maps + the closed-form solve of Model.cpp:849-858.
 // `fixed[k]` holds, for k < UMPA_KFIX, the per-frame map at the window that does not move with the shift
 // (W[s_k](p) in 'sam' mode, mean_k(p) in 'ref' mode); `movmap` is the other per-frame map.
-template <int KIND>
+// load base[byte_off / 8]: a wave-uniform base with a 32-bit per-lane byte offset is the
+// `global_load v, v_off, s[base:base+1]` addressing mode -- no 64-bit address arithmetic on the VALU
+__device__ __forceinline__ double ld_off(const UMPA_GLOBAL double* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const UMPA_GLOBAL double*>(reinterpret_cast<const UMPA_GLOBAL char*>(base) + byte_off);
+}
+
+// NA > 0: the number of frames is a compile-time constant (<= UMPA_KFIX) and every map plane is addressable
+// with 32-bit byte offsets: straight-line code, no per-frame tests.  NA == 0: any frame count.
+template <int KIND, int NA>
 __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, const ReplayArgs& R, int ref_mode,
                                            int i, int j, size_t tpx, int si, int sj,
                                            const double* fixed, double& cost, Fit& fit)
@@ -467,21 +476,41 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     // window positions (Model.cpp:688-701)
     const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
     const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
-    const double t1 = gp(M.SamSq)[xs], t3 = gp(M.RefSq)[xr];
     const double rwt = 1.0 / (double)m.Na;                          // wave-uniform: scalar
+    double t1, t3;
+    if (NA > 0) {
+        t1 = ld_off(gp(M.SamSq), (unsigned)xs * 8u);
+        t3 = ld_off(gp(M.RefSq), (unsigned)xr * 8u);
+    } else {
+        t1 = gp(M.SamSq)[xs];
+        t3 = gp(M.RefSq)[xr];
+    }
     if (KIND == 1) {
-        const double t2 = gp(M.RefM2)[xr], t6 = gp(M.RefM6)[xr];
+        double t2, t6, t4 = 0.0;
         const size_t plane = (size_t)M.H * M.W;
-        const UMPA_GLOBAL double* __restrict__ mov = gp(ref_mode ? M.WS : M.MR) + (ref_mode ? xs : xr);
-        double mv[UMPA_KFIX];
+        if (NA > 0) {
+            const unsigned br = (unsigned)xr * 8u, bm = (unsigned)(ref_mode ? xs : xr) * 8u;
+            t2 = ld_off(gp(M.RefM2), br);
+            t6 = ld_off(gp(M.RefM6), br);
+            const UMPA_GLOBAL double* __restrict__ mov = gp(ref_mode ? M.WS : M.MR);
+            double mv[NA > 0 ? NA : 1];
 #pragma unroll
-        for (int k = 0; k < UMPA_KFIX; k++) mv[k] = k < m.Na ? mov[k * plane] : 0.0;    // all loads in flight together
-        double t4 = 0.0;
+            for (int k = 0; k < NA; k++) mv[k] = ld_off(mov + k * plane, bm);          // all loads in flight together
 #pragma unroll
-        for (int k = 0; k < UMPA_KFIX; k++) if (k < m.Na) t4 += mv[k] * fixed[k];
-        if (m.Na > UMPA_KFIX) {
-            const UMPA_GLOBAL double* __restrict__ fx = gp(ref_mode ? M.MR : M.WS) + (ref_mode ? xr : xs);
-            for (int k = UMPA_KFIX; k < m.Na; k++) t4 += mov[k * plane] * fx[k * plane];
+            for (int k = 0; k < NA; k++) t4 += mv[k] * fixed[k];
+        } else {
+            t2 = gp(M.RefM2)[xr];
+            t6 = gp(M.RefM6)[xr];
+            const UMPA_GLOBAL double* __restrict__ mov = gp(ref_mode ? M.WS : M.MR) + (ref_mode ? xs : xr);
+            double mv[UMPA_KFIX];
+#pragma unroll
+            for (int k = 0; k < UMPA_KFIX; k++) mv[k] = k < m.Na ? mov[k * plane] : 0.0;
+#pragma unroll
+            for (int k = 0; k < UMPA_KFIX; k++) if (k < m.Na) t4 += mv[k] * fixed[k];
+            if (m.Na > UMPA_KFIX) {
+                const UMPA_GLOBAL double* __restrict__ fx = gp(ref_mode ? M.MR : M.WS) + (ref_mode ? xr : xs);
+                for (int k = UMPA_KFIX; k < m.Na; k++) t4 += mov[k * plane] * fx[k * plane];
+            }
         }
         // Model.cpp:849-858 with one reciprocal instead of the reference's three divisions by the same
         // determinant and the division by wt (1-ulp level differences; the bar is 1e-5).  The dark-field
@@ -500,7 +529,7 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     return UMPA_ST_OK;
 }
 
-template <int KIND>
+template <int KIND, int NA>
 __global__ void __launch_bounds__(UMPA_WALK_THREADS, 3)
 replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
 {
@@ -512,12 +541,13 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
     const size_t tpx = (size_t)(xi * A.step0 - R.drow0) * R.N1d + (size_t)xj * A.step1;
     if (A.cover && gp(A.cover)[px] < A.thr) return;
     const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
-    double fixed[UMPA_KFIX];
+    constexpr int NFIX = NA > 0 ? NA : UMPA_KFIX;
+    double fixed[NFIX];
     if (KIND == 1) {
         const size_t plane = (size_t)M.H * M.W;
         const UMPA_GLOBAL double* __restrict__ fx = gp(m.ref_mode ? M.MR : M.WS) + (size_t)i * M.W + j;
 #pragma unroll
-        for (int k = 0; k < UMPA_KFIX; k++) fixed[k] = k < m.Na ? fx[k * plane] : 0.0;
+        for (int k = 0; k < NFIX; k++) fixed[k] = (NA > 0 || k < m.Na) ? fx[k * plane] : 0.0;
     }
     const LdsMemo<UMPA_WALK_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
     Walk w;
@@ -527,7 +557,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
         Fit fit = w.live;
         for (int n = 0; n < 18; n++) {
             double c = 0.0;
-            eval_lookup<KIND>(m, M, R, m.ref_mode, i, j, tpx, (n % 5) - 2, (n / 5) - 2, fixed, c, fit);
+            eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, (n % 5) - 2, (n / 5) - 2, fixed, c, fit);
             csum += c;
         }
         w.out = csum; w.live = fit; w.phase = PH_DONE; w.status = 1;
@@ -535,7 +565,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
     while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
-        const int st = eval_lookup<KIND>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, c, fit);
+        const int st = eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, c, fit);
         walk_feed(w, memo, st, c, fit);
     }
     double nb[16];
@@ -774,8 +804,18 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
         dim3 blk(64, 4), grd((A.N1 + 63) / 64, (R.rows + 3) / 4);
         tic(4);
-        if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1>), grd, blk, 0, s, dev, M, R, A);
-        else hipLaunchKernelGGL((replay_walk_kernel<0>), grd, blk, 0, s, dev, M, R, A);
+        // frame count as a template constant where the map planes are 32-bit addressable (eval_lookup)
+        const bool small = (size_t)M.H * M.W * sizeof(double) < ((size_t)1 << 32);
+#define UMPA_REPLAY_NA(n) case n: hipLaunchKernelGGL((replay_walk_kernel<1, n>), grd, blk, 0, s, dev, M, R, A); break;
+        if (kind == 1 && small && dev.Na <= UMPA_KFIX) {
+            switch (dev.Na) {
+                UMPA_REPLAY_NA(1) UMPA_REPLAY_NA(2) UMPA_REPLAY_NA(3) UMPA_REPLAY_NA(4) UMPA_REPLAY_NA(5) UMPA_REPLAY_NA(6)
+                UMPA_REPLAY_NA(7) UMPA_REPLAY_NA(8) UMPA_REPLAY_NA(9) UMPA_REPLAY_NA(10) UMPA_REPLAY_NA(11) UMPA_REPLAY_NA(12)
+                UMPA_REPLAY_NA(13) UMPA_REPLAY_NA(14) UMPA_REPLAY_NA(15) UMPA_REPLAY_NA(16)
+            }
+        } else if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1, 0>), grd, blk, 0, s, dev, M, R, A);
+        else hipLaunchKernelGGL((replay_walk_kernel<0, 0>), grd, blk, 0, s, dev, M, R, A);
+#undef UMPA_REPLAY_NA
         toc();
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
