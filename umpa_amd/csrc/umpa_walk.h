@@ -53,7 +53,7 @@ struct Walk {
     int phase;
     int g;             // gather cursor 0..15
     int ip, jp;        // quadrant of the 4x4 neighbourhood
-    int lo_up;
+    double c0;         // cost at the centre (memo cell 12)
     int status;
     Fit live, kept;    // *args and args_copy of Optim.cpp:249,265
     double out, uv0, uv1;
@@ -162,7 +162,7 @@ __device__ inline void walk_begin(Walk& w, Memo memo, double u0, double u1)
     w.phase = PH_CENTRE;
     w.g = 0;
     w.ip = w.jp = 0;
-    w.lo_up = 0;
+    w.c0 = 0.0;
     w.status = 0;
     w.live.t = w.live.v = 0.0;                                  // Model.cpp:68,74
     w.kept = w.live;
@@ -201,10 +201,16 @@ __device__ inline void memo_shift(Memo d, int axis, int dir)
 // Deliver the result of the pending request (status `st`, cost `val`, fit parameters `fit`)
 // and advance to the next request, to PH_FIT (4x4 neighbourhood complete: walk_finish does the
 // sub-pixel fit once for the whole wave) or to PH_DONE (failed).
+//
+// Written for a SIMD machine: the value is stored into the memo first, and the search for the next
+// request then reads the two neighbours of the centre along the current axis back from the memo,
+// whether they were just evaluated or memoised -- the reference's "fresh" (Optim.cpp:294,325) and
+// "memoised" (:300,331) comparisons are the same expression on the same numbers, so only the
+// snapshot `args_copy = *args` (:296,327) depends on which one it was.  The centre value rides in a
+// register (`c0`): after a move it is the neighbour that was just compared.
 template <class Memo>
 __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit)
 {
-    enum { PC_CHECK, PC_LO, PC_HI, PC_DECIDE, PC_GATHER };
     w.n++;                                                      // Ncalls counts failed calls too (Optim.cpp:263-264)
     if (!(st & UMPA_ST_OK)) {                                   // any failed call returns at once, outputs as they stand
         w.status = st;
@@ -212,118 +218,105 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
         return;
     }
     w.live = fit;
-    int pc = PC_CHECK, hi_up = 0;
-    switch (w.phase) {
-    case PH_CENTRE:                                             // Optim.cpp:262-265
-        memo[12] = val;
-        w.kept = w.live;
-        pc = PC_CHECK;
-        break;
-    case PH_LO:                                                 // Optim.cpp:287-297
-        memo[w.axis ? 7 : 11] = val;
-        w.lo_up = val > memo[12] + UMPA_TIE;
-        if (!w.lo_up) w.kept = w.live;
-        pc = PC_HI;
-        break;
-    case PH_HI:                                                 // Optim.cpp:320-328
-        memo[w.axis ? 17 : 13] = val;
-        hi_up = val > memo[12] - UMPA_TIE;
-        if (!hi_up) w.kept = w.live;
-        pc = PC_DECIDE;
-        break;
-    default: {                                                  // PH_GATHER, Optim.cpp:353-378
+    bool cap_test = true;                                       // the `while (Ncalls < MAX_CALLS)` header, Optim.cpp:267
+    bool scan = false;
+    if (w.phase == PH_GATHER) {                                 // Optim.cpp:353-378
         const int r = w.g >> 2, c = w.g & 3;
         memo[5 * (w.ip + r) + w.jp + c] = val;                  // the `a` entry is this memo cell (Optim.cpp:357-362)
-        if (val < memo[12]) {                                   // missed a lower value: hard restart
+        if (val < w.c0) {                                       // missed a lower value: hard restart
             w.ci += w.ip + r - 2;
             w.cj += w.jp + c - 2;
             for (int q = 0; q < 25; q++) memo[q] = -1.0;
             memo[12] = val;
+            w.c0 = val;
             w.live = w.kept;                                    // stale on purpose (Optim.cpp:373)
             w.found0 = w.found1 = 0;
-            pc = PC_LO;                                         // `goto start` skips the call-cap test
+            cap_test = false;                                   // `goto start` skips the call-cap test
         } else {
             w.g++;
-            pc = PC_GATHER;
+            scan = true;
         }
-    } break;
+    } else {
+        bool keep;
+        int cell;
+        if (w.phase == PH_CENTRE) {                             // Optim.cpp:262-265
+            cell = 12;
+            w.c0 = val;
+            keep = true;
+        } else if (w.phase == PH_LO) {                          // Optim.cpp:287-297
+            cell = w.axis ? 7 : 11;
+            keep = !(val > w.c0 + UMPA_TIE);
+        } else {                                                // PH_HI, Optim.cpp:320-328
+            cell = w.axis ? 17 : 13;
+            keep = !(val > w.c0 - UMPA_TIE);
+        }
+        memo[cell] = val;
+        if (keep) w.kept = w.live;
     }
 
-    for (;;) {
+    while (!scan) {
+        if (cap_test && w.n >= UMPA_CALL_CAP) {
+            w.status = st & ~UMPA_ST_OK;                        // Optim.cpp:477
+            w.phase = PH_DONE;
+            return;
+        }
+        cap_test = true;
         const int lo = w.axis ? 7 : 11, hi = w.axis ? 17 : 13;
-        if (pc == PC_CHECK) {                                   // while(Ncalls < MAX_CALLS), Optim.cpp:267
-            if (w.n >= UMPA_CALL_CAP) {
-                w.status = st & ~UMPA_ST_OK;                    // Optim.cpp:477
-                w.phase = PH_DONE;
-                return;
-            }
-            pc = PC_LO;
+        const double dlo = memo[lo], dhi = memo[hi];
+        if (dlo < -0.5) {
+            w.phase = PH_LO;
+            w.req_i = w.ci - (w.axis ? 1 : 0);
+            w.req_j = w.cj - (w.axis ? 0 : 1);
+            return;
         }
-        if (pc == PC_LO) {
-            if (memo[lo] < -0.5) {
-                w.phase = PH_LO;
-                w.req_i = w.ci - (w.axis ? 1 : 0);
-                w.req_j = w.cj - (w.axis ? 0 : 1);
-                return;
-            }
-            w.lo_up = memo[lo] > memo[12] + UMPA_TIE;            // Optim.cpp:300
-            pc = PC_HI;
+        if (dhi < -0.5) {
+            w.phase = PH_HI;
+            w.req_i = w.ci + (w.axis ? 1 : 0);
+            w.req_j = w.cj + (w.axis ? 0 : 1);
+            return;
         }
-        if (pc == PC_HI) {
-            if (memo[hi] < -0.5) {
-                w.phase = PH_HI;
-                w.req_i = w.ci + (w.axis ? 1 : 0);
-                w.req_j = w.cj + (w.axis ? 0 : 1);
-                return;
-            }
-            hi_up = memo[hi] > memo[12] - UMPA_TIE;              // Optim.cpp:331
-            pc = PC_DECIDE;
-        }
-        if (pc == PC_DECIDE) {
-            if (w.lo_up && hi_up) {                             // Optim.cpp:334-417
-                const int f = memo[lo] < memo[hi] ? -1 : 1;
-                if (w.axis) w.found1 = f; else w.found0 = f;
-                const int other = w.axis ? w.found0 : w.found1;
-                if (!other) {
-                    w.axis ^= 1;
-                    pc = PC_CHECK;
-                    continue;
-                }
-                w.ip = memo[17] < memo[7] ? 1 : 0;              // Optim.cpp:344-345
-                w.jp = memo[13] < memo[11] ? 1 : 0;
-                w.g = 0;
-                pc = PC_GATHER;
-            } else {                                            // Optim.cpp:420-474
-                w.uv0 = w.ci;
-                w.uv1 = w.cj;
-                w.out = memo[12];
-                int up = w.lo_up;
-                if (!hi_up && !w.lo_up) up = memo[hi] < memo[lo];
-                const int dir = up ? 1 : -1;
-                if (w.axis) w.ci += dir; else w.cj += dir;
-                memo_shift(memo, w.axis, dir);
-                if (w.axis) w.found0 = 0; else w.found1 = 0;
-                pc = PC_CHECK;
+        const bool lo_up = dlo > w.c0 + UMPA_TIE;               // Optim.cpp:294,300
+        const bool hi_up = dhi > w.c0 - UMPA_TIE;               // Optim.cpp:325,331
+        if (lo_up && hi_up) {                                   // Optim.cpp:334-417
+            const int f = dlo < dhi ? -1 : 1;
+            if (w.axis) w.found1 = f; else w.found0 = f;
+            const int other = w.axis ? w.found0 : w.found1;
+            if (!other) {
+                w.axis ^= 1;
                 continue;
             }
+            w.ip = memo[17] < memo[7] ? 1 : 0;                  // Optim.cpp:344-345
+            w.jp = memo[13] < memo[11] ? 1 : 0;
+            w.g = 0;
+            scan = true;
+        } else {                                                // Optim.cpp:420-474
+            w.uv0 = w.ci;
+            w.uv1 = w.cj;
+            w.out = w.c0;
+            bool up = lo_up;
+            if (!hi_up && !lo_up) up = dhi < dlo;
+            const int dir = up ? 1 : -1;
+            if (w.axis) w.ci += dir; else w.cj += dir;
+            memo_shift(memo, w.axis, dir);
+            w.c0 = up ? dhi : dlo;                              // the new centre is the neighbour stepped onto
+            if (w.axis) w.found0 = 0; else w.found1 = 0;
         }
-        // PC_GATHER: fill the 4x4 neighbourhood from the memo, asking for what is missing
-        while (w.g < 16) {
-            const int r = w.g >> 2, c = w.g & 3;
-            const double known = memo[5 * (w.ip + r) + w.jp + c];
-            if (known < -0.9) {
-                w.phase = PH_GATHER;
-                w.req_i = w.ci + w.ip + r - 2;
-                w.req_j = w.cj + w.jp + c - 2;
-                return;
-            }
-            w.g++;
-        }
-        w.live = w.kept;                                        // Optim.cpp:386
-        w.status = st;
-        w.phase = PH_FIT;
-        return;
     }
+    // fill the 4x4 neighbourhood from the memo, asking for what is missing
+    while (w.g < 16) {
+        const int r = w.g >> 2, c = w.g & 3;
+        const double known = memo[5 * (w.ip + r) + w.jp + c];
+        if (known < -0.9) {
+            w.phase = PH_GATHER;
+            w.req_i = w.ci + w.ip + r - 2;
+            w.req_j = w.cj + w.jp + c - 2;
+            return;
+        }
+        w.g++;
+    }
+    w.live = w.kept;                                            // Optim.cpp:386
+    w.status = st;
+    w.phase = PH_FIT;
 }
 
 // Sub-pixel refinement for the lanes whose walk completed (Optim.cpp:386-410).  `nb` receives the
