@@ -51,7 +51,8 @@ struct Walk {
     int found0, found1;
     int n;             // cost calls so far (minimizer_debug::Ncalls)
     int phase;
-    int g;             // gather cursor 0..15
+    int g;             // gather: the cell 0..15 being asked for
+    unsigned need;     // gather: cells of the 4x4 neighbourhood still unknown (bit g)
     int ip, jp;        // quadrant of the 4x4 neighbourhood
     double c0;         // cost at the centre (memo cell 12)
     int status;
@@ -161,6 +162,7 @@ __device__ inline void walk_begin(Walk& w, Memo memo, double u0, double u1)
     w.n = 0;
     w.phase = PH_CENTRE;
     w.g = 0;
+    w.need = 0;
     w.ip = w.jp = 0;
     w.c0 = 0.0;
     w.status = 0;
@@ -233,7 +235,7 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
             w.found0 = w.found1 = 0;
             cap_test = false;                                   // `goto start` skips the call-cap test
         } else {
-            w.g++;
+            w.need &= w.need - 1;
             scan = true;
         }
     } else {
@@ -287,7 +289,14 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
             }
             w.ip = memo[17] < memo[7] ? 1 : 0;                  // Optim.cpp:344-345
             w.jp = memo[13] < memo[11] ? 1 : 0;
-            w.g = 0;
+            // which cells of the 4x4 neighbourhood are still unknown: nothing but this walk's own
+            // requests changes the memo until the gather ends, so one look is enough
+            const int q0 = 5 * w.ip + w.jp;
+            unsigned need = 0;
+#pragma unroll
+            for (int g = 0; g < 16; g++)
+                if (memo[q0 + 5 * (g >> 2) + (g & 3)] < -0.9) need |= 1u << g;
+            w.need = need;
             scan = true;
         } else {                                                // Optim.cpp:420-474
             w.uv0 = w.ci;
@@ -302,17 +311,13 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
             if (w.axis) w.found0 = 0; else w.found1 = 0;
         }
     }
-    // fill the 4x4 neighbourhood from the memo, asking for what is missing
-    while (w.g < 16) {
-        const int r = w.g >> 2, c = w.g & 3;
-        const double known = memo[5 * (w.ip + r) + w.jp + c];
-        if (known < -0.9) {
-            w.phase = PH_GATHER;
-            w.req_i = w.ci + w.ip + r - 2;
-            w.req_j = w.cj + w.jp + c - 2;
-            return;
-        }
-        w.g++;
+    // fill the 4x4 neighbourhood, asking for what is missing in the reference's order (Optim.cpp:353-362)
+    if (w.need) {
+        w.g = __ffs(w.need) - 1;
+        w.phase = PH_GATHER;
+        w.req_i = w.ci + w.ip + (w.g >> 2) - 2;
+        w.req_j = w.cj + w.jp + (w.g & 3) - 2;
+        return;
     }
     w.live = w.kept;                                            // Optim.cpp:386
     w.status = st;
