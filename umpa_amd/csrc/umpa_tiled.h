@@ -471,8 +471,9 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     if (sj <= -ms) return UMPA_ST_BOUND | UMPA_ST_DIM;
     if (sj >= ms) return UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
     const int UJ = 2 * ms - 1;
-    const size_t slot = (size_t)(si + ms - 1) * UJ + (sj + ms - 1);
-    const double t5 = gp(R.table)[slot * R.slot_stride + tpx];
+    const unsigned slot = (unsigned)((si + ms - 1) * UJ + (sj + ms - 1));
+    // slot_stride < 2^32 (tiled_match bounds the row chunk): one 32x32->64-bit multiply-add
+    const double t5 = gp(R.table)[(size_t)slot * (unsigned)R.slot_stride + tpx];
     // window positions (Model.cpp:688-701)
     const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
     const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
@@ -760,6 +761,11 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
     if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
     if (rows_chunk > N0d) rows_chunk = ((long)N0d + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+    {   // eval_lookup multiplies the slot number by a 32-bit slot stride (rows_chunk * N1d)
+        const long cap = (long)(0xffffffffull / (size_t)N1d) / UMPA_TILE * UMPA_TILE;
+        if (cap < UMPA_TILE) return (int)hipErrorInvalidValue;
+        if (rows_chunk > cap) rows_chunk = cap;
+    }
     const size_t table_need = (size_t)UJ * UJ * rows_chunk * N1d;
     if (st.table_cap < table_need) {
         if (st.table) (void)hipFree(st.table);

@@ -265,13 +265,14 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
         cap_test = true;
         const int lo = w.axis ? 7 : 11, hi = w.axis ? 17 : 13;
         const double dlo = memo[lo], dhi = memo[hi];
-        if (dlo < -0.5) {
+        const int unknown = (dlo < -0.5 ? 1 : 0) | (dhi < -0.5 ? 2 : 0);    // both reads in flight before any branch
+        if (unknown & 1) {
             w.phase = PH_LO;
             w.req_i = w.ci - (w.axis ? 1 : 0);
             w.req_j = w.cj - (w.axis ? 0 : 1);
             return;
         }
-        if (dhi < -0.5) {
+        if (unknown) {
             w.phase = PH_HI;
             w.req_i = w.ci + (w.axis ? 1 : 0);
             w.req_j = w.cj + (w.axis ? 0 : 1);
