@@ -530,13 +530,20 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     return UMPA_ST_OK;
 }
 
+// Workgroup = UMPA_REPLAY_ROWS waves, each on 64 consecutive pixels of one row.  A workgroup keeps its LDS until
+// its slowest wave has finished, so small workgroups refill the CU sooner (the walk lengths differ).
+#ifndef UMPA_REPLAY_ROWS
+#define UMPA_REPLAY_ROWS 1
+#endif
+#define UMPA_REPLAY_THREADS (64 * UMPA_REPLAY_ROWS)
+
 template <int KIND, int NA>
-__global__ void __launch_bounds__(UMPA_WALK_THREADS, 3)
+__global__ void __launch_bounds__(UMPA_REPLAY_THREADS, 3)
 replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
 {
-    __shared__ double memo_lds[25 * UMPA_WALK_THREADS];
+    __shared__ double memo_lds[25 * UMPA_REPLAY_THREADS];
     const int xj = blockIdx.x * 64 + threadIdx.x;
-    const int xi = R.row0 + blockIdx.y * 4 + threadIdx.y;
+    const int xi = R.row0 + blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
     if (xi >= R.row0 + R.rows || xj >= A.N1) return;
     const size_t px = (size_t)xi * A.N1 + xj;
     const size_t tpx = (size_t)(xi * A.step0 - R.drow0) * R.N1d + (size_t)xj * A.step1;
@@ -550,7 +557,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
 #pragma unroll
         for (int k = 0; k < NFIX; k++) fixed[k] = (NA > 0 || k < m.Na) ? fx[k * plane] : 0.0;
     }
-    const LdsMemo<UMPA_WALK_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
+    const LdsMemo<UMPA_REPLAY_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
     if (R.ablate & 1) {                                             // diagnostics: the lookups without the walk
@@ -808,7 +815,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         R.table = st.table; R.slot_stride = CA.slot_stride; R.drow0 = drow0; R.N1d = N1d;
         R.row0 = xi_lo; R.rows = xi_hi - xi_lo;
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
-        dim3 blk(64, 4), grd((A.N1 + 63) / 64, (R.rows + 3) / 4);
+        dim3 blk(64, UMPA_REPLAY_ROWS), grd((A.N1 + 63) / 64, (R.rows + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
         tic(4);
         // frame count as a template constant where the map planes are 32-bit addressable (eval_lookup)
         const bool small = (size_t)M.H * M.W * sizeof(double) < ((size_t)1 << 32);
