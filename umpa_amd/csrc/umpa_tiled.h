@@ -447,7 +447,8 @@ struct ReplayArgs {
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE_REPLAY): 1 = 18 fixed lookups instead of the walk, 2 = no sub-pixel fit
 };
 
-#define UMPA_KFIX 16          // frames whose fixed-window map value is kept in registers by replay_walk
+#define UMPA_KFIX 16          // frames whose fixed-window map value is kept in registers by replay_walk (any frame count)
+#define UMPA_KTEMPL 24        // largest frame count with its own replay_walk instantiation (all of them in registers)
 
 // One "cost evaluation" of the walk: table lookup + maps + the closed-form solve of Model.cpp:849-858.
 // `fixed[k]` holds, for k < UMPA_KFIX, the per-frame map at the window that does not move with the shift
@@ -459,7 +460,7 @@ __device__ __forceinline__ double ld_off(const UMPA_GLOBAL double* base, unsigne
     return *reinterpret_cast<const UMPA_GLOBAL double*>(reinterpret_cast<const UMPA_GLOBAL char*>(base) + byte_off);
 }
 
-// NA > 0: the number of frames is a compile-time constant (<= UMPA_KFIX) and every map plane is addressable
+// NA > 0: the number of frames is a compile-time constant (<= UMPA_KTEMPL) and every map plane is addressable
 // with 32-bit byte offsets: straight-line code, no per-frame tests.  NA == 0: any frame count.
 template <int KIND, int NA>
 __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, const ReplayArgs& R, int ref_mode,
@@ -820,11 +821,12 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         // frame count as a template constant where the map planes are 32-bit addressable (eval_lookup)
         const bool small = (size_t)M.H * M.W * sizeof(double) < ((size_t)1 << 32);
 #define UMPA_REPLAY_NA(n) case n: hipLaunchKernelGGL((replay_walk_kernel<1, n>), grd, blk, 0, s, dev, M, R, A); break;
-        if (kind == 1 && small && dev.Na <= UMPA_KFIX) {
+        if (kind == 1 && small && dev.Na <= UMPA_KTEMPL) {
             switch (dev.Na) {
                 UMPA_REPLAY_NA(1) UMPA_REPLAY_NA(2) UMPA_REPLAY_NA(3) UMPA_REPLAY_NA(4) UMPA_REPLAY_NA(5) UMPA_REPLAY_NA(6)
                 UMPA_REPLAY_NA(7) UMPA_REPLAY_NA(8) UMPA_REPLAY_NA(9) UMPA_REPLAY_NA(10) UMPA_REPLAY_NA(11) UMPA_REPLAY_NA(12)
-                UMPA_REPLAY_NA(13) UMPA_REPLAY_NA(14) UMPA_REPLAY_NA(15) UMPA_REPLAY_NA(16)
+                UMPA_REPLAY_NA(13) UMPA_REPLAY_NA(14) UMPA_REPLAY_NA(15) UMPA_REPLAY_NA(16) UMPA_REPLAY_NA(17) UMPA_REPLAY_NA(18)
+                UMPA_REPLAY_NA(19) UMPA_REPLAY_NA(20) UMPA_REPLAY_NA(21) UMPA_REPLAY_NA(22) UMPA_REPLAY_NA(23) UMPA_REPLAY_NA(24)
             }
         } else if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1, 0>), grd, blk, 0, s, dev, M, R, A);
         else hipLaunchKernelGGL((replay_walk_kernel<0, 0>), grd, blk, 0, s, dev, M, R, A);
