@@ -124,6 +124,15 @@ int umpa_hip_match_region(umpa_hip_model *m, int start0, int step0, int N0,
 int umpa_hip_spmin(int device, const double *a16, double *pos2, double *value);
 int umpa_hip_spmin_quad(int device, const double *a16, double *pos2, double *value);
 
+/* Bad-pixel repair of result maps, the epilogue of the reference's align.UMPA_normal / align.UMPA_nobias
+ * (UMPA/align.py:51-52, 115-116, 661-732): pixels of `in` outside [lo, hi] are "bad"; each of `iterations`
+ * passes replaces every bad pixel by the median of its 2*ndims neighbours as they were before the pass
+ * (ndims = 2: along H and W; ndims = 1: along W only; edges reflect), everything else is copied.
+ * `in`/`out` hold `nimg` images of H x W doubles (may be the same buffer); host pointers, or device
+ * pointers with UMPA_HIP_F_DEVICE_IO.  The call returns when the result is in `out`. */
+int umpa_hip_correct_bad_pixels(const double *in, double *out, long nimg, int H, int W, int ndims,
+                                double lo, double hi, int iterations, int device, int flags, void *stream);
+
 /* instrumentation used by bench.py for the roofline line: when enabled every kernel launch is
  * bracketed by HIP events on its launch stream; collect() waits for them and folds them into
  * per-kernel totals (returns the number of distinct kernels), read() returns one total. */

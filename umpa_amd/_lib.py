@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "device_count", "last_error", "version", "create", "destroy", "set_window", "set_subpx",
     "set_reference_shift", "coverage", "coverage_region", "cost", "min", "match_region",
     "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "last_path",
-    "update_frames",
+    "update_frames", "correct_bad_pixels",
 ]
 
 
@@ -77,6 +77,8 @@ class Native:
             f("timing_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), _dp, _ip])
             f("last_path", C.c_int, [C.c_void_p])
             f("update_frames", C.c_int, [C.c_void_p, _dpp, _dpp])
+            f("correct_bad_pixels", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
+                                              C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p])
         else:
             f("spmin", C.c_double, [_dp, _dp])
             f("spmin_quad", C.c_double, [_dp, _dp])

@@ -297,4 +297,48 @@ __global__ void spfit_kernel(const double* a, double* io, int quad)
     io[0] = x; io[1] = y;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bad-pixel repair of a result map (UMPA/align.py:661-732), the epilogue of align.UMPA_normal / UMPA_nobias.
+// `bad` marks the pixels of the ORIGINAL image outside [lo, hi]; one pass replaces each of them by the
+// median of its 2*ndims neighbours in `src` (edges reflect: -1 -> 1, n -> n-2), everything else is copied.
+// All reads of a pass come from `src` (numpy gathers all neighbours before it writes).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+badpix_mark_kernel(const double* __restrict__ img, unsigned char* __restrict__ bad, size_t n, double lo, double hi)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const double v = gp(img)[q];
+    gpw(bad)[q] = (v < lo || v > hi) ? 1 : 0;
+}
+
+__device__ __forceinline__ void sort2(double& a, double& b) { const double lo = fmin(a, b), hi = fmax(a, b); a = lo; b = hi; }
+
+__global__ void __launch_bounds__(256)
+badpix_pass_kernel(const double* __restrict__ src, double* __restrict__ dst, const unsigned char* __restrict__ bad,
+                   size_t nimg, int H, int W, int ndims)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t plane = (size_t)H * W;
+    if (q >= nimg * plane) return;
+    double v = gp(src)[q];
+    if (gp(bad)[q]) {
+        const size_t base = q / plane * plane;
+        const int r = (int)((q - base) / W), c = (int)((q - base) % W);
+        const int cl = c == 0 ? 1 : c - 1, ch = c + 1 == W ? W - 2 : c + 1;
+        double a = gp(src)[base + (size_t)r * W + cl], b = gp(src)[base + (size_t)r * W + ch];
+        if (ndims == 1) {
+            v = (a + b) / 2.0;                                        // median of two = their mean
+        } else {
+            const int rl = r == 0 ? 1 : r - 1, rh = r + 1 == H ? H - 2 : r + 1;
+            double cc = gp(src)[base + (size_t)rl * W + c], d = gp(src)[base + (size_t)rh * W + c];
+            const bool nan = a != a || b != b || cc != cc || d != d;  // numpy.median: NaN if any
+            sort2(a, b); sort2(cc, d); sort2(a, cc); sort2(b, d);     // a = min, d = max
+            v = nan ? __builtin_nan("") : (b + cc) / 2.0;             // the two middle values, any order
+        }
+    }
+    gpw(dst)[q] = v;
+}
+
 } // namespace umpa

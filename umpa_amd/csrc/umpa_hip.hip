@@ -571,6 +571,52 @@ static int spfit(int device, const double* a16, double* pos2, double* value, int
 int umpa_hip_spmin(int device, const double* a16, double* pos2, double* value) { return spfit(device, a16, pos2, value, 0); }
 int umpa_hip_spmin_quad(int device, const double* a16, double* pos2, double* value) { return spfit(device, a16, pos2, value, 1); }
 
+int umpa_hip_correct_bad_pixels(const double* in, double* out, long nimg, int H, int W, int ndims,
+                                double lo, double hi, int iterations, int device, int flags, void* stream)
+{
+    if (!in || !out) return fail(UMPA_HIP_E_ARG, "null argument");
+    if (nimg < 1 || H < 1 || W < 2 || (ndims == 2 && H < 2) || (ndims != 1 && ndims != 2) || iterations < 0)
+        return fail(UMPA_HIP_E_ARG, "correct_bad_pixels: bad shape %ld x %d x %d, ndims %d, iterations %d", nimg, H, W, ndims, iterations);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(UMPA_HIP_E_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device), UMPA_HIP_E_DEVICE);
+    hipStream_t s = (hipStream_t)stream;
+    const bool dev_io = (flags & UMPA_HIP_F_DEVICE_IO) != 0;
+    const size_t n = (size_t)nimg * H * W, bytes = n * sizeof(double);
+    // scratch: [a][b] ping-pong images + the mask; with device I/O `out` is one of the two images
+    double *a = nullptr, *b = nullptr;
+    unsigned char* bad = nullptr;
+    void* blob = nullptr;
+    const size_t need = (dev_io ? bytes : 2 * bytes) + n;
+    if (hipMalloc(&blob, need) != hipSuccess) return fail(UMPA_HIP_E_NOMEM, "correct_bad_pixels: %zu bytes of scratch", need);
+    hipError_t e = hipSuccess;
+    if (dev_io) {
+        a = out; b = (double*)blob; bad = (unsigned char*)blob + bytes;
+        if (a != in) e = hipMemcpyAsync(a, in, bytes, hipMemcpyDeviceToDevice, s);
+    } else {
+        a = (double*)blob; b = a + n; bad = (unsigned char*)blob + 2 * bytes;
+        e = hipMemcpyAsync(a, in, bytes, hipMemcpyHostToDevice, s);
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (e == hipSuccess) { hipLaunchKernelGGL(umpa::badpix_mark_kernel, dim3(grid), dim3(256), 0, s, a, bad, n, lo, hi); e = hipGetLastError(); }
+    double *src = a, *dst = b;
+    for (int it = 0; it < iterations && e == hipSuccess; it++) {
+        hipLaunchKernelGGL(umpa::badpix_pass_kernel, dim3(grid), dim3(256), 0, s, src, dst, bad, (size_t)nimg, H, W, ndims);
+        e = hipGetLastError();
+        std::swap(src, dst);
+    }
+    // the result is in `src`
+    if (e == hipSuccess) {
+        if (dev_io) { if (src != out) e = hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, s); }
+        else e = hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);                 // the scratch is freed below
+    (void)hipFree(blob);
+    if (e != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "correct_bad_pixels: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int umpa_hip_timing_enable(umpa_hip_model* m, int on)
 {
     if (!m) return fail(UMPA_HIP_E_ARG, "null model");
