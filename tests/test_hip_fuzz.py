@@ -1,0 +1,67 @@
+"""
+Seeded random sweep of the HIP path against the CPU oracle (GPU box only): shapes, frame counts, window
+sizes, search ranges, both models, both coordinate conventions, the three sub-pixel modes, steps, start
+shifts, masks, and both kernel paths.  Same bar as everywhere (conftest.assert_parity): err / Ncalls /
+integer minimum bit-exact, float maps <= 1e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def namespaces():
+    from umpa_amd import _lib, model
+    from oracle import cpu_model
+    if _lib.hip().device_count() < 1:
+        pytest.fail("no HIP device: the GPU tests cannot run (there is no CPU fallback)")
+    return model, cpu_model.port
+
+
+def _configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for q in range(n):
+        Nw = int(rng.integers(1, 9))
+        ms = int(rng.integers(1, 8))
+        P = Nw + ms
+        c = dict(Nw=Nw, ms=ms, K=int(rng.choice([1, 2, 3, 5, 7, 10, 13, 16, 17, 20, 24, 25, 29])),
+                 H=2 * P + int(rng.integers(8, 90)), W=2 * P + int(rng.integers(8, 110)),
+                 df=bool(rng.integers(0, 2)), assign=str(rng.choice(["sam", "ref"])),
+                 subpx=int(rng.choice([-1, -1, 0, 1])), step=int(rng.choice([1, 1, 1, 2, 3])),
+                 dxdy=None if rng.random() < 0.7 else (int(rng.integers(-1, 2)), int(rng.integers(-1, 2))),
+                 mask=bool(rng.random() < 0.2), force=int(rng.choice([0, 0, 0, 2])),      # 2 = UMPA_HIP_F_FORCE_DIRECT
+                 amp=float(rng.uniform(0.2, max(0.3, ms - 1.2))), seed=1000 + q)
+        out.append(c)
+    return out
+
+
+CONFIGS = _configs(60, 20261003)
+
+
+@pytest.mark.parametrize("c", CONFIGS, ids=["%02d" % q for q in range(len(CONFIGS))])
+def test_random_configuration(namespaces, c):
+    from umpa_amd.synth import make_stack
+    hip_ns, port_ns = namespaces
+    sam, ref, _ = make_stack(c["H"], c["W"], c["K"], c["ms"], df=c["df"], seed=c["seed"], amplitude=c["amp"], order=1)
+    mask = None
+    if c["mask"]:
+        rng = np.random.default_rng(c["seed"])
+        mask = (rng.random(sam.shape) < 0.93).astype(np.float64)
+    name = "UMPAModelDF" if c["df"] else "UMPAModelNoDF"
+    models = []
+    for ns in (hip_ns, port_ns):
+        m = getattr(ns, name)(sam, ref, mask_list=mask, window_size=c["Nw"], max_shift=c["ms"])
+        m.assign_coordinates = c["assign"]
+        m.sub_pixel_mode = c["subpx"]
+        models.append(m)
+    g, o = models
+    g._force = c["force"]
+    kw = dict(step=c["step"], quiet=True)
+    if c["dxdy"] is not None:
+        kw["dxdy"] = c["dxdy"]
+    got, want = g.match(**kw), o.match(**kw)
+    assert_parity(got, want, c["ms"], str(c), subpx=c["subpx"], allow_illposed=0.05)
