@@ -53,6 +53,11 @@ extern "C" {
 #define UMPA_HIP_F_FORCE_DIRECT   2  /* use the general direct kernel even where the tiled fast path applies */
 #define UMPA_HIP_F_FORCE_TILED    4  /* fail with E_UNSUPPORTED instead of silently using the direct kernel */
 #define UMPA_HIP_F_PLANAR         8  /* values is [nparam][N0*N1] (one plane per map) instead of the reference's [N0*N1][nparam] */
+#define UMPA_HIP_F_REUSE_REF_MAPS 16 /* the reference stack is the one of this model's previous match (match_unbiased, a projection
+                                        series against one reference): the tiled path keeps its reference-side maps and recomputes
+                                        only the sample side.  For frames the model owns it also checks that itself
+                                        (umpa_hip_update_frames / set_window invalidate); for borrowed device frames the caller vouches.
+                                        Results are identical with and without. */
 
 typedef struct umpa_hip_model umpa_hip_model;
 

@@ -283,3 +283,36 @@ def test_degenerate_sizes_on_device(hip_ns, port_ns):
     assert_parity(g, o, 4, "3-row output")
     with pytest.raises(RuntimeError, match="Empty ROI"):
         hip_ns.UMPAModelDF(np.ones((2, 12, 30)), np.ones((2, 12, 30)), window_size=2, max_shift=4).match(quiet=True)
+
+
+def test_reference_side_maps_are_reused_and_invalidated(hip_ns):
+    """UMPA_HIP_F_REUSE_REF_MAPS: a second match of one model recomputes only the sample-side maps; swapping the
+    sample stack keeps the reference side, swapping the reference stack or the window drops it.  Every result must
+    equal the one of a freshly built model, bit for bit."""
+    from umpa_amd.synth import make_stack
+    samA, refA, _ = make_stack(120, 140, 6, 4, df=True, seed=5, amplitude=1.5)
+    samB, refB, _ = make_stack(120, 140, 6, 4, df=True, seed=9, amplitude=2.0)
+
+    def fresh(sam, ref, Nw=3):
+        return hip_ns.UMPAModelDF(sam, ref, window_size=Nw, max_shift=4).match(quiet=True)
+
+    def same(a, b):
+        for k in ("err", "debug_Ncalls", "T", "df", "dx", "dy", "f"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+    m = hip_ns.UMPAModelDF(samA, refA, window_size=3, max_shift=4)
+    first = m.match(quiet=True)
+    assert m._lib.last_path(m._handle) == 2                            # the tiled path, where the maps live
+    same(m.match(quiet=True), first)                                   # second match: reference side reused
+    m.update_frames(sam_list=samB)
+    same(m.match(quiet=True), fresh(samB, refA))                       # new sample stack, old reference maps
+    m.update_frames(ref_list=refB)
+    same(m.match(quiet=True), fresh(samB, refB))                       # new reference stack: recomputed
+    m.Nw = 2
+    same(m.match(quiet=True), _with_nw(hip_ns, samB, refB, 2))        # new window: every map recomputed
+
+
+def _with_nw(hip_ns, sam, ref, nw):
+    m = hip_ns.UMPAModelDF(sam, ref, window_size=3, max_shift=4)
+    m.Nw = nw
+    return m.match(quiet=True)

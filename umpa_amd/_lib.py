@@ -16,7 +16,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "libumpa_hip.so")
 
 ST_OK, ST_BOUND, ST_DIM, ST_POSITIVE = 1, 2, 4, 8
 F_DEVICE_FRAMES = 1
-F_DEVICE_IO, F_FORCE_DIRECT, F_FORCE_TILED, F_PLANAR = 1, 2, 4, 8
+F_DEVICE_IO, F_FORCE_DIRECT, F_FORCE_TILED, F_PLANAR, F_REUSE_REF_MAPS = 1, 2, 4, 8, 16
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

@@ -227,7 +227,7 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s)
     if (can_tile && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
         TiledTimers tt;
         int rc = tiled_match(m->tiled, m->dev(), m->kind, m->dims[0], m->dims[1], A, s,
-                             m->timing ? &tt : nullptr);
+                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0);
         if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
         if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
         if (m->timing) {
@@ -335,6 +335,7 @@ int umpa_hip_update_frames(umpa_hip_model* m, double* const* sam, double* const*
     if (!m) return fail(UMPA_HIP_E_ARG, "null model");
     if (!m->owns_frames) return fail(UMPA_HIP_E_ARG, "the model borrows device frames; update them in place instead");
     HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    if (ref) m->tiled.ref_maps_ok = false;
     for (int k = 0; k < m->Na; k++) {
         const size_t n = (size_t)m->dims[2 * k] * m->dims[2 * k + 1] * sizeof(double);
         if (sam) HIP_TRY(hipMemcpyAsync(m->d_sam[k], sam[k], n, hipMemcpyHostToDevice, m->stream), UMPA_HIP_E_DEVICE);

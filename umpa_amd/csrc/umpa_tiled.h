@@ -79,8 +79,11 @@ struct PrepCfg {
 
 template <int KIND, int NW>
 __global__ void __launch_bounds__(256)
-prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
+prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
 {
+    // sides: bit 0 = the sample-side maps (SamSq, WS_k), bit 1 = the reference-side maps (RefSq, RefM2, RefM6, MR_k).
+    // A model whose reference stack has not changed since the last match only recomputes the sample side.
+    const bool do_ref = (sides & 2) != 0;
     using C = PrepCfg<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* rawS = reinterpret_cast<double*>(smem_raw);
@@ -119,7 +122,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
     auto fetch = [&](int k) {
         const FrameDesc f = load_frame(m.frames, k);
 #pragma unroll
-        for (int n = 0; n < NS; n++) { ps[n] = gp(f.sam)[s_g[n]]; pr[n] = gp(f.ref)[s_g[n]]; }
+        for (int n = 0; n < NS; n++) { ps[n] = gp(f.sam)[s_g[n]]; pr[n] = do_ref ? gp(f.ref)[s_g[n]] : 0.0; }
     };
     fetch(0);
     for (int k = 0; k < m.Na; k++) {
@@ -131,7 +134,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
         if (k + 1 < m.Na) fetch(k + 1);
         __syncthreads();
         // H stage (along columns): items (which, cb, r), r fastest: 2 x 4 x Q
-        for (int it = tid; it < 2 * 4 * C::Q; it += C::NT) {
+        for (int it = tid; it < (do_ref ? 2 : 1) * 4 * C::Q; it += C::NT) {
             const int r = it % C::Q, rest = it / C::Q, cb = rest & 3, which = rest >> 2;
             const double* src = (which ? rawR : rawS) + (cb * C::CB) * C::QP + r;
             double lin_[C::CB], sq_[C::CB];
@@ -158,6 +161,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
         for (int q = 0; q < 2; q++) {
             const int it = tid + q * C::NT;
             const int c = it & 31, rb = (it >> 5) & 3, ptype = it >> 7;
+            if (q == 1 && !do_ref) continue;                             // q = 1 holds the two reference planes
             if (KIND == 0 && (ptype == 0 || ptype == 2)) continue;       // NoDF needs only the squares
             double out[C::CB];
             fir_block<NW, C::CB>(hpl + ptype * C::HPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
@@ -181,6 +185,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty)
         const int it = tid + q * C::NT;
         const int c = it & 31, rb = (it >> 5) & 3, ptype = it >> 7;
         const int gc = c0 + c;
+        if (q == 1 && !do_ref) continue;
 #pragma unroll
         for (int o = 0; o < C::CB; o++) {
             const int gr = r0 + rb * C::CB + o;
@@ -593,6 +598,11 @@ struct TiledState {
     Sep1D sep;
     bool separable = false;
     int sep_nw = -1;
+    // the reference-side maps in `maps` are current for this (kind, frame count, plane size): set by tiled_match,
+    // cleared by whoever changes the reference frames or the window
+    bool ref_maps_ok = false;
+    int ref_kind = -1, ref_K = 0;
+    size_t ref_plane = 0;
 };
 
 struct TiledTimers { int n = 0; int name[64]; hipEvent_t t0[64], t1[64]; };
@@ -607,6 +617,7 @@ inline bool tiled_factor_window(TiledState& st, const double* win, int Nw)
 {
     const int S = 2 * Nw + 1;
     st.separable = false;
+    st.ref_maps_ok = false;                                           // every map is a filter with this window
     st.sep_nw = Nw;
     if (Nw > UMPA_MAX_NW) return false;
     const double pivot = win[Nw * S + Nw];
@@ -627,6 +638,7 @@ inline void tiled_release(TiledState& st)
     if (st.table) (void)hipFree(st.table);
     st.maps = st.table = nullptr;
     st.maps_cap = st.table_cap = 0;
+    st.ref_maps_ok = false;
 }
 
 inline int pick_ub(int UJ)
@@ -699,7 +711,7 @@ inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A,
 }
 
 template <int KIND, int NW>
-inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& sep, hipStream_t s)
+inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& sep, int sides, hipStream_t s)
 {
     using C = PrepCfg<NW>;
     static bool attr_set[64] = {};                                    // the attribute is per device
@@ -713,7 +725,7 @@ inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& s
     }
     const int ntx = (M.W - 2 * NW + C::T - 1) / C::T, nty = (M.H - 2 * NW + C::T - 1) / C::T;
     const int total = ntx * nty, grid = ((total + 7) / 8) * 8;
-    hipLaunchKernelGGL((prep_maps_kernel<KIND, NW>), dim3(grid), dim3(C::NT), C::LDS, s, dev, M, sep, ntx, nty);
+    hipLaunchKernelGGL((prep_maps_kernel<KIND, NW>), dim3(grid), dim3(C::NT), C::LDS, s, dev, M, sep, ntx, nty, sides);
     return hipGetLastError();
 }
 
@@ -741,8 +753,9 @@ inline size_t tiled_table_budget()
 }
 
 // One match of a region on the tiled path.  Returns 0, -3 (allocation) or a positive hipError_t.
+// `reuse_ref_maps`: the caller vouches that the reference frames are those of the previous call (it owns them).
 inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const RegionArgs& A,
-                       hipStream_t s, TiledTimers* tt)
+                       hipStream_t s, TiledTimers* tt, bool reuse_ref_maps)
 {
     const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1;
     const size_t plane = (size_t)H * W;
@@ -750,9 +763,11 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     if (st.maps_cap < nmaps * plane) {
         if (st.maps) (void)hipFree(st.maps);
         st.maps = nullptr; st.maps_cap = 0;
+        st.ref_maps_ok = false;
         if (hipMalloc((void**)&st.maps, nmaps * plane * sizeof(double)) != hipSuccess) return -3;
         st.maps_cap = nmaps * plane;
     }
+    if (st.ref_kind != kind || st.ref_K != K || st.ref_plane != plane) st.ref_maps_ok = false;
     Maps M;
     M.H = H; M.W = W;
     M.SamSq = st.maps; M.RefSq = st.maps + plane;
@@ -787,10 +802,13 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
 
     hipError_t e = hipErrorInvalidValue;
     tic(2);
-    if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, s))) }
-    else { UMPA_NW_SWITCH(Nw, (e = launch_prep<0, NWC>(dev, M, st.sep, s))) }
+    const int sides = (reuse_ref_maps && st.ref_maps_ok) ? 1 : 3;
+    st.ref_maps_ok = false;
+    if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, sides, s))) }
+    else { UMPA_NW_SWITCH(Nw, (e = launch_prep<0, NWC>(dev, M, st.sep, sides, s))) }
     toc();
     if (e != hipSuccess) return (int)e;
+    st.ref_maps_ok = true; st.ref_kind = kind; st.ref_K = K; st.ref_plane = plane;
 
     int ub = pick_ub(UJ);
     { const char* e = getenv("UMPA_HIP_UB"); if (e) ub = atoi(e); }      // tuning override: 9, 8, 7 or 5

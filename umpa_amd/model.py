@@ -370,7 +370,10 @@ class UMPAModelBase:
         args = [self._handle, s0[0], s0[2], N0, s1[0], s1[2], N1, vp(values), self.Nparam, vp(uv), vp(err),
                 vp(covermap), float(thr), vp(dd), vp(da), vp(dn)]
         if self._lib.is_hip:
-            args += [self._match_flags() | (_lib.F_PLANAR if planar else 0), None]
+            flags = self._match_flags() | (_lib.F_PLANAR if planar else 0)
+            if not hasattr(self._sam[0], "data_ptr"):               # frames owned by the library: it knows when the
+                flags |= _lib.F_REUSE_REF_MAPS                      # reference stack changed (update_frames, Nw)
+            args += [flags, None]
         else:
             if uv is None:
                 uv = np.zeros((N0, N1, 2), dtype=NPDOUBLE)
