@@ -43,11 +43,14 @@ struct RegionArgs {
     int row_base;                       // first region row covered by `kern` (row chunking of DFKernel launches)
 };
 
-// descriptor k, read through the global address space (member-wise: a struct copy across address
-// spaces does not compile in the host pass)
+// descriptor k, read through the CONSTANT address space: the table is written before any kernel runs and k is
+// wave-uniform, so this is an s_load into SGPRs.  Read as ordinary global memory it becomes a vector load followed
+// by s_waitcnt vmcnt(0) -- which also waits for every frame load (and table store) still in flight.
+// (member-wise: a struct copy across address spaces does not compile in the host pass)
+#define UMPA_CONSTANT __attribute__((address_space(4)))
 __device__ __forceinline__ FrameDesc load_frame(const FrameDesc* frames, int k)
 {
-    const UMPA_GLOBAL FrameDesc* g = gp(frames) + k;
+    const UMPA_CONSTANT FrameDesc* g = (const UMPA_CONSTANT FrameDesc*)frames + k;
     FrameDesc f;
     f.sam = g->sam; f.ref = g->ref; f.mask = g->mask;
     f.H = g->H; f.W = g->W; f.pi = g->pi; f.pj = g->pj;
