@@ -111,3 +111,39 @@ def test_projection_farm_on_cpu_workers():
         want = cpu_model.port.UMPAModelDF(sams[p], ref, window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
         for k in ("f", "T", "dx", "dy", "df", "err"):
             np.testing.assert_array_equal(got[p][k], want[k])
+
+
+def _gpu_worker(rank, world, port, tmp):
+    """Two ranks, one process each, both on the one GPU of the test box (the 8-GPU run is the driver's): slabs are
+    matched by the HIP path and gathered over gloo; rank 0 checks against the unsharded HIP result."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      UMPA_HIP_DEVICE="0")
+    import torch.distributed as dist
+    from umpa_amd import model, sharding
+    from umpa_amd.synth import make_stack
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nw, ms = 3, 4
+        sam, ref, _ = make_stack(150, 170, 4, ms, df=True, seed=11, amplitude=2.0)
+        n_out = sam.shape[1] - 2 * (Nw + ms)
+        keys = ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls")
+        res, (r0, r1) = sharding.match_rows(model.UMPAModelDF, sam, ref, Nw, ms, world, rank)
+        whole = sharding.gather_rows({k: res[k] for k in keys}, n_out, dst=0)
+        if rank == 0:
+            full = model.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms).match(quiet=True)
+            for k in keys:
+                np.testing.assert_array_equal(whole[k], full[k], err_msg=k)
+            assert full["err"].mean() > 0.5
+            open(os.path.join(tmp, "gpu_ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_row_sharding_on_the_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "gpu_ok").exists()
