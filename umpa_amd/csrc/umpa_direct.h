@@ -103,7 +103,9 @@ __device__ __forceinline__ double blur_at(const UMPA_GLOBAL double* img, const U
 
 // One cost evaluation at pixel (i,j), shift (si rows, sj cols).  KIND: 0 NoDF, 1 DF, 2 DFKernel
 // (NoDF arithmetic on a reference blurred on the fly, Model.cpp:997-1151).
-template <int KIND, bool MASK>
+// NWC > 0: the window half-width is a compile-time constant (the column loop unrolls, all loads of a window row are
+// in flight together); NWC == 0: any window.
+template <int KIND, bool MASK, int NWC = 0>
 __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int si, int sj,
                                            double& cost, Fit& fit,
                                            const UMPA_GLOBAL double* kern = nullptr, size_t kstride = 0)
@@ -117,7 +119,7 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
     int ri = i, rj = j, qi = i, qj = j;                  // Model.cpp:408-421 / :688-701
     if (m.ref_mode) { qi -= si; qj -= sj; } else { ri += si; rj += sj; }
 
-    const int Nw = m.Nw, S = 2 * Nw + 1, pad = m.padding;
+    const int Nw = NWC > 0 ? NWC : m.Nw, S = 2 * Nw + 1, pad = m.padding;
     double t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
     double wt = MASK ? 0.0 : (double)m.Na;               // Model.cpp:425,:711 / :463,:777
 
@@ -155,16 +157,23 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
             if (KIND != 2) {
                 // two columns per step: 16-byte loads (the L1/TA path is half-rate for 8-byte ones); the terms are
                 // still accumulated in the reference's order
-                for (; b + 1 < S; b += 2) {
-                    const pair_t r2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(R + off + b);
-                    const pair_t q2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(Q + off + b);
+                auto pair_step = [&](int c) {
+                    const pair_t r2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(R + off + c);
+                    const pair_t q2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(Q + off + c);
                     pair_t mr2 = {0.0, 0.0}, mq2 = {0.0, 0.0};
                     if (MASK) {
-                        mr2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(MR + off + b);
-                        mq2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(MQ + off + b);
+                        mr2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(MR + off + c);
+                        mq2 = *reinterpret_cast<const UMPA_GLOBAL pair_t*>(MQ + off + c);
                     }
-                    term(wrow[b], r2[0], q2[0], mr2[0], mq2[0]);
-                    term(wrow[b + 1], r2[1], q2[1], mr2[1], mq2[1]);
+                    term(wrow[c], r2[0], q2[0], mr2[0], mq2[0]);
+                    term(wrow[c + 1], r2[1], q2[1], mr2[1], mq2[1]);
+                };
+                if constexpr (NWC > 0) {
+#pragma unroll
+                    for (int c = 0; c < 2 * NWC; c += 2) pair_step(c);
+                    b = 2 * NWC;
+                } else {
+                    for (; b + 1 < S; b += 2) pair_step(b);
                 }
             }
             for (; b < S; b++) {
@@ -228,7 +237,7 @@ __device__ __forceinline__ int xcd_band_remap(int lin, int total)
 
 #define UMPA_WALK_THREADS (UMPA_DIRECT_BX * UMPA_DIRECT_BY)
 
-template <int KIND, bool MASK>
+template <int KIND, bool MASK, int NWC>
 __global__ void __launch_bounds__(UMPA_WALK_THREADS, 3)
 match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
 {
@@ -255,7 +264,7 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
     while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
-        const int st = eval_direct<KIND, MASK>(m, i, j, w.req_i, w.req_j, c, fit, kern, A.kern_stride);
+        const int st = eval_direct<KIND, MASK, NWC>(m, i, j, w.req_i, w.req_j, c, fit, kern, A.kern_stride);
         walk_feed(w, memo, st, c, fit);
     }
     double nb[16];

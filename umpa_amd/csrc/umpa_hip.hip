@@ -153,16 +153,37 @@ int check_region(const umpa_hip_model* m, int start0, int step0, int N0, int sta
     return 0;
 }
 
-template <int KIND, bool MASK>
-void launch_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
+template <int KIND, bool MASK, int NWC>
+void launch_direct_nw(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
 {
     const int nbx = (A.N1 + UMPA_DIRECT_BX - 1) / UMPA_DIRECT_BX;
     const int nby = (A.N0 + UMPA_DIRECT_BY - 1) / UMPA_DIRECT_BY;
     const int total = nbx * nby;
     const int grid = ((total + 7) / 8) * 8;          // multiple of 8 so the XCD band remap covers every tile
     ScopedTimer t(m, s, KN_DIRECT);
-    hipLaunchKernelGGL((match_direct_kernel<KIND, MASK>), dim3(grid), dim3(UMPA_DIRECT_BX, UMPA_DIRECT_BY), 0, s,
+    hipLaunchKernelGGL((match_direct_kernel<KIND, MASK, NWC>), dim3(grid), dim3(UMPA_DIRECT_BX, UMPA_DIRECT_BY), 0, s,
                        m->dev(), A, nbx, nby);
+}
+
+// the window half-widths of practical use get their own instantiation (unrolled window rows); the kernel-dark-field
+// model and anything else run the generic one
+template <int KIND, bool MASK>
+void launch_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
+{
+    if constexpr (KIND != 2) {
+        switch (m->Nw) {
+        case 1: return launch_direct_nw<KIND, MASK, 1>(m, A, s);
+        case 2: return launch_direct_nw<KIND, MASK, 2>(m, A, s);
+        case 3: return launch_direct_nw<KIND, MASK, 3>(m, A, s);
+        case 4: return launch_direct_nw<KIND, MASK, 4>(m, A, s);
+        case 5: return launch_direct_nw<KIND, MASK, 5>(m, A, s);
+        case 6: return launch_direct_nw<KIND, MASK, 6>(m, A, s);
+        case 7: return launch_direct_nw<KIND, MASK, 7>(m, A, s);
+        case 8: return launch_direct_nw<KIND, MASK, 8>(m, A, s);
+        default: break;
+        }
+    }
+    launch_direct_nw<KIND, MASK, 0>(m, A, s);
 }
 
 int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s)
