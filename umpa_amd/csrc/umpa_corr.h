@@ -1,0 +1,282 @@
+// umpa_corr.h -- corr_volume, the dominant kernel of the tiled path: the exhaustive table
+//   t5[u][p] = sum_k W[ s_k(.) r_k(.+u) ](p)          (the only term of Model.cpp:763-772 that couples
+// pixel and shift spatially) for all (2 max_shift - 1)^2 integer shifts u of a row chunk.
+//
+// One workgroup = one (tile, pass): a tile is TR x TC output pixels, a pass is one row offset oi and a
+// batch of UB column offsets.  Per frame k the workgroup needs the q-region (tile + window halo) of the
+// fixed-window stack A and the same region, widened by the batch, of the moving stack B.
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4): the frames go from L2 straight into LDS, no VGPRs, no
+// ds_write.  A wave-instruction writes 64 consecutive 16-byte pieces, the SOURCE address is per lane, so
+// the LDS image is a plain row-major patch [row][column pair] filled in piece order; a ring of NSLOT
+// frame slots keeps NSLOT-1 frames in flight behind the one being multiplied (one raw s_barrier per
+// frame, counted s_waitcnt vmcnt).  Product threads own one patch row and QB consecutive columns and
+// read them as column pairs (ds_read_b128): with an odd number of pieces per image row the 16 lanes of
+// a b128 group (consecutive rows) hit 16 different 16-byte slots -- conflict free.
+//
+// After the last frame the UB product planes go to LDS (transposed, [column][row], odd pitch), get the
+// window's column filter in place and its row filter on the way to the table, as before.
+#pragma once
+#include "umpa_direct.h"
+
+namespace umpa {
+
+#define UMPA_TILE 32
+#define UMPA_MAX_NW 8
+#define UMPA_LDS_BUDGET (160 * 1024)
+
+struct Sep1D {                       // the two 1-D factors of the window, win[a][b] = hr[a]*hc[b]
+    double hr[2 * UMPA_MAX_NW + 1];
+    double hc[2 * UMPA_MAX_NW + 1];
+};
+
+// Reads in[t*stride], t < CB + 2NW, and returns the CB filtered values out[o] = sum_tap h[tap] in[o+tap].
+// All inputs are fetched before the first FMA so the LDS latency is paid once per item, not once per read.
+template <int NW, int CB>
+__device__ __forceinline__ void fir_block(const double* __restrict__ in, int stride, const double* h, double* out)
+{
+    constexpr int S = 2 * NW + 1;
+    double v[CB + S - 1];
+#pragma unroll
+    for (int t = 0; t < CB + S - 1; t++) v[t] = in[t * stride];
+#pragma unroll
+    for (int o = 0; o < CB; o++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int tap = 0; tap < S; tap++) acc = fma(h[tap], v[o + tap], acc);
+        out[o] = acc;
+    }
+}
+
+struct CorrArgs {
+    double* table;            // [(2ms-1)^2][rows][N1]
+    size_t slot_stride;       // rows * N1
+    int org0, org1;           // frame coordinates of output pixel (0,0) of the REGION
+    int row0, rows;           // this launch covers region rows [row0, row0+rows)
+    int N1;
+    int sigma;                // +1: B = ref sits at p+u ('sam' mode); -1: B = sam sits at p-u ('ref' mode)
+    int ntx, nty;
+    int ablate;               // diagnostics only (UMPA_HIP_ABLATE): 1 no global loads, 4 no products, 8 no filters
+};
+
+#define UMPA_LDS_AS __attribute__((address_space(3)))
+
+// Tile = TR x TC output pixels (TR = 32 rows); NT threads; LDSB = LDS bytes one workgroup may use
+// (160 KiB / workgroups per CU).
+template <int NW, int UB, int TC, int NT>
+struct CorrCfg {
+    static constexpr int TR = UMPA_TILE, S = 2 * NW + 1;
+    static constexpr int LDSB = (NT >= 512) ? UMPA_LDS_BUDGET : UMPA_LDS_BUDGET / 2;
+    static constexpr int QR = TR + 2 * NW, QC = TC + 2 * NW;  // q-region (tile + window halo): rows, columns
+    static constexpr int QP = QR | 1;                     // odd pitch of the transposed product planes ([column][row])
+    static constexpr int PPL = QC * QP;                   // one product plane
+    // product blocking: a thread owns one q row and QB consecutive columns (QB even: column pairs)
+    static constexpr int QB = (QR * ((QC + 3) / 4) <= NT) ? 4 : (QR * ((QC + 5) / 6) <= NT) ? 6 : 8;
+    static constexpr int NQB = (QC + QB - 1) / QB;        // column blocks
+    static constexpr int AC = NQB * QB;                   // columns the product threads address (>= QC; the excess is never stored)
+    static constexpr int NBP = (QB + UB) / 2;             // B column pairs a thread reads: ceil((QB+UB-1)/2)
+    static constexpr int BW = (QC + UB) & ~1;             // B columns staged, even
+    static constexpr int PA = (QC / 2) | 1, PB = (BW / 2) | 1;   // 16-byte pieces per image row: odd
+    static constexpr int NPIECE = QR * (PA + PB);         // pieces of one staged frame: A image then B image
+    static constexpr int NPT = (NPIECE + NT - 1) / NT;    // LDS-DMA instructions per thread and frame
+    static constexpr int SLOT = NPT * NT * 2;             // doubles per frame slot (every lane of every instruction writes)
+    // the last block's threads read past the end of their image row, on the last row past the image:
+    static constexpr int OVER = 2 * (NQB * (QB / 2) - (QB / 2) + NBP) - 2 * PB;
+    static constexpr int TAIL = NPIECE * 2 + (OVER > 0 ? OVER : 0);             // doubles of the last slot that are touched
+    static constexpr int NSLOT_FIT = (LDSB / 8 - (TAIL > SLOT ? TAIL - SLOT : 0)) / SLOT;
+    static constexpr int NSLOT = NSLOT_FIT > 4 ? 4 : NSLOT_FIT;               // ring depth: NSLOT-1 frames in flight
+    static constexpr int RING = NSLOT * SLOT + (TAIL > SLOT ? TAIL - SLOT : 0);
+    static constexpr int LDS_DOUBLES = RING > UB * PPL ? RING : UB * PPL;
+    static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
+    static constexpr int CB = 8;                          // outputs per filter item
+    static constexpr int HITEMS = UB * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
+    static constexpr bool OK = NSLOT >= 2 && UB * PPL * 8 <= LDSB && QR * NQB <= NT && (NSLOT - 1) * NPT < 64 &&
+                               LDS_DOUBLES * 8 <= LDSB;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// workgroup barrier that does NOT drain the vector-memory counter (LDS-DMA of later frames stays in flight);
+// the compiler must not move LDS accesses across it
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int NW, int UB, int TC, int NT>
+__global__ void __launch_bounds__(NT, 2)
+corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
+{
+    using C = CorrCfg<NW, UB, TC, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+
+    // One workgroup = one (tile, pass).  The passes of a tile read the same A patch and overlapping B patches; they
+    // get consecutive slots on ONE XCD (blocks b, b+8, ... share an XCD) so that those re-reads are served by that
+    // XCD's L2 instead of crossing the fabric once per pass.  Placement only affects speed.
+    const int ms = m.ms, UJ = 2 * ms - 1;
+    const int nbatch = (UJ + UB - 1) / UB, npass = UJ * nbatch;
+    const int ntiles = A.ntx * A.nty, tiles_per_xcd = (ntiles + 7) >> 3;
+    const int seq = blockIdx.x >> 3;                                  // position in this XCD's queue
+    const int lin = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;   // contiguous band of tiles per XCD
+    const int pass = seq % npass;
+    if (seq / npass >= tiles_per_xcd || lin >= ntiles) return;
+    const int tx = lin % A.ntx, ty = lin / A.ntx;
+    const int tid = threadIdx.x;
+    const int prow0 = A.row0 + ty * C::TR, pcol0 = tx * TC;           // first output pixel of the tile (region coords)
+    const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
+    const int H = gp(m.frames)->H, W = gp(m.frames)->W;
+    const int oi = pass / nbatch - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
+
+    // ---- LDS-DMA slots of this thread: piece p = tid + n*NT of the frame image (A rows, then B rows); its source
+    // is 16 bytes = two adjacent columns of one frame row.  Pieces past the image (padding of the last instruction,
+    // the pad piece of an image row) read a clamped address and land in bytes nobody uses.
+    unsigned src_off[C::NPT];                                         // byte offset inside a frame
+    unsigned src_isB = 0;                                             // bit n: piece n comes from the B stack
+#pragma unroll
+    for (int n = 0; n < C::NPT; n++) {
+        const int p = tid + n * NT;
+        int r, c;
+        bool isB = p >= C::QR * C::PA;
+        if (!isB) { r = p / C::PA; c = 2 * (p % C::PA); }
+        else {
+            const int q = min(p - C::QR * C::PA, C::QR * C::PB - 1);
+            r = q / C::PB + oi; c = 2 * (q % C::PB) + oj0;
+        }
+        const int gr = min(max(fr0 + r, 0), H - 1), gc = min(max(fc0 + c, 0), W - 2);
+        src_off[n] = (unsigned)(gr * W + gc) * 8u;
+        if (isB) src_isB |= 1u << n;
+    }
+    const unsigned wave_piece0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);   // first piece of this wave's instruction 0
+
+    auto issue_frame = [&](int k) {                                   // frame k -> ring slot k % NSLOT
+        const FrameDesc fd = load_frame(m.frames, k);
+        const UMPA_GLOBAL char* gA = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fd.sam : fd.ref);
+        const UMPA_GLOBAL char* gB = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fd.ref : fd.sam);
+        UMPA_LDS_AS char* slot = (UMPA_LDS_AS char*)(lds + (k % C::NSLOT) * C::SLOT);
+#pragma unroll
+        for (int n = 0; n < C::NPT; n++) {
+            const UMPA_GLOBAL char* src = ((src_isB >> n) & 1u ? gB : gA) + src_off[n];
+            __builtin_amdgcn_global_load_lds(src, slot + (size_t)(wave_piece0 + n * NT) * 16, 16, 0, 0);
+        }
+    };
+
+    // product-stage ownership: (qb, r), r fastest
+    const int pr = tid % C::QR, pqb = tid / C::QR;
+    const bool pactive = pqb < C::NQB;
+    typedef double pair_t __attribute__((ext_vector_type(2)));
+    double acc[C::QB][UB];
+#pragma unroll
+    for (int t = 0; t < C::QB; t++)
+#pragma unroll
+        for (int u = 0; u < UB; u++) acc[t][u] = 0.0;
+
+    const int K = m.Na;
+    constexpr int D = C::NSLOT - 1;                                   // frames in flight behind the one in use
+    if (!(A.ablate & 1)) {
+#pragma unroll
+        for (int f = 0; f < D; f++)
+            if (f < K) issue_frame(f);
+    }
+    for (int k = 0; k < K; k++) {
+        // frames k .. k+D-1 have been issued, in order: frame k has landed when at most (D-1)*NPT are outstanding
+        if (k + D - 1 < K) wait_vmcnt<(D - 1) * C::NPT>(); else wait_vmcnt<0>();
+        lds_barrier();                                                // everyone's pieces of frame k are in; slot (k-1)%NSLOT is free
+        if (k + D < K && !(A.ablate & 1)) issue_frame(k + D);
+        if (pactive && !(A.ablate & 4)) {
+            const pair_t* la = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT) + pr * C::PA + pqb * (C::QB / 2);
+            const pair_t* lb = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT) + C::QR * C::PA + pr * C::PB + pqb * (C::QB / 2);
+            pair_t av[C::QB / 2], bv[C::NBP];
+#pragma unroll
+            for (int t = 0; t < C::QB / 2; t++) av[t] = la[t];
+#pragma unroll
+            for (int t = 0; t < C::NBP; t++) bv[t] = lb[t];
+#pragma unroll
+            for (int t = 0; t < C::QB; t++)
+#pragma unroll
+                for (int u = 0; u < UB; u++) acc[t][u] = fma(av[t >> 1][t & 1], bv[(t + u) >> 1][(t + u) & 1], acc[t][u]);
+        }
+    }
+    if (A.ablate & 8) return;
+    {
+        // ---- all frames of this pass are in: product planes -> LDS, H filter, V filter, store
+        const int nu = min(UB, ms - oj0);                             // offsets oj0 .. oj0+nu-1 are real
+        __syncthreads();                                              // frames consumed: the region becomes product planes
+        if (pactive) {
+#pragma unroll
+            for (int t = 0; t < C::QB; t++) {
+                const int c = pqb * C::QB + t;
+                if (c < C::QC) {
+#pragma unroll
+                    for (int u = 0; u < UB; u++) lds[u * C::PPL + c * C::QP + pr] = acc[t][u];
+                }
+            }
+        }
+        __syncthreads();
+        // H stage (along columns), results kept in registers, then written in place
+        double hres[C::HROUNDS][C::CB];
+#pragma unroll
+        for (int rd = 0; rd < C::HROUNDS; rd++) {
+            const int it = tid + rd * NT;
+            if (it < C::HITEMS) {
+                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
+                fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rd = 0; rd < C::HROUNDS; rd++) {
+            const int it = tid + rd * NT;
+            if (it < C::HITEMS) {
+                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
+                double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
+#pragma unroll
+                for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
+            }
+        }
+        __syncthreads();
+        // V stage (along rows) and store: items (u, rb, column pair), pair fastest -> coalesced table rows, and two
+        // adjacent columns per lane so that the table is written with 16-byte stores (twice the rate of 8-byte ones).
+        // Odd N1 breaks the 16-byte alignment of the rows: then the two columns are stored separately.
+        constexpr int VP = TC / 2, VITEMS2 = UB * (C::TR / C::CB) * VP, VROUNDS2 = (VITEMS2 + NT - 1) / NT;
+        const bool vec_ok = (A.N1 & 1) == 0;
+#pragma unroll
+        for (int rd = 0; rd < VROUNDS2; rd++) {
+            const int it = tid + rd * NT;
+            if (it < VITEMS2) {
+                const int cp = it % VP, rest = it / VP, rb = rest % (C::TR / C::CB), u = rest / (C::TR / C::CB);
+                if (u < nu) {
+                    const int c = 2 * cp;
+                    double out0[C::CB], out1[C::CB];
+                    fir_block<NW, C::CB>(lds + u * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out0);
+                    fir_block<NW, C::CB>(lds + u * C::PPL + (c + 1) * C::QP + rb * C::CB, 1, sep.hr, out1);
+                    const int ui = A.sigma * oi, uj = A.sigma * (oj0 + u);
+                    const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
+                    const int col = pcol0 + c;
+                    UMPA_GLOBAL double* dst = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 + rb * C::CB - A.row0) * A.N1 + col;
+#pragma unroll
+                    for (int o = 0; o < C::CB; o++) {
+                        const int row = prow0 + rb * C::CB + o;               // region row
+                        if (row < A.row0 + A.rows) {
+                            if (vec_ok && col + 1 < A.N1) {
+                                pair_t v2; v2[0] = out0[o]; v2[1] = out1[o];
+                                *reinterpret_cast<UMPA_GLOBAL pair_t*>(dst + (size_t)o * A.N1) = v2;
+                            } else {
+                                if (col < A.N1) dst[(size_t)o * A.N1] = out0[o];
+                                if (col + 1 < A.N1) dst[(size_t)o * A.N1 + 1] = out1[o];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace umpa

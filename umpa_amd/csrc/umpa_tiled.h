@@ -26,17 +26,9 @@
 // along rows read and write consecutive 8-byte words (no bank conflicts for ds_read_b64).
 #pragma once
 #include "umpa_direct.h"
+#include "umpa_corr.h"
 
 namespace umpa {
-
-#define UMPA_TILE 32
-#define UMPA_MAX_NW 8
-#define UMPA_LDS_BUDGET (160 * 1024)
-
-struct Sep1D {                       // the two 1-D factors of the window, win[a][b] = hr[a]*hc[b]
-    double hr[2 * UMPA_MAX_NW + 1];
-    double hc[2 * UMPA_MAX_NW + 1];
-};
 
 struct Maps {                        // prep_maps outputs, each a full H x W plane (borders unused)
     double* SamSq;                   // sum_k W[s_k^2]                      -> t1
@@ -47,24 +39,6 @@ struct Maps {                        // prep_maps outputs, each a full H x W pla
     double* MR;                      // [K] planes mean_k = W[r_k]/sum(w)           (DF)
     int H, W;
 };
-
-// Reads in[t*stride], t < CB + 2NW, and returns the CB filtered values out[o] = sum_tap h[tap] in[o+tap].
-// All inputs are fetched before the first FMA so the LDS latency is paid once per item, not once per read.
-template <int NW, int CB>
-__device__ __forceinline__ void fir_block(const double* __restrict__ in, int stride, const double* h, double* out)
-{
-    constexpr int S = 2 * NW + 1;
-    double v[CB + S - 1];
-#pragma unroll
-    for (int t = 0; t < CB + S - 1; t++) v[t] = in[t * stride];
-#pragma unroll
-    for (int o = 0; o < CB; o++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int tap = 0; tap < S; tap++) acc = fma(h[tap], v[o + tap], acc);
-        out[o] = acc;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // prep_maps
@@ -194,249 +168,6 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
             if (ptype == 1) gpw(M.SamSq)[g] = acc[q][o];
             else if (ptype == 3) gpw(M.RefSq)[g] = acc[q][o];
             else if (ptype == 2 && KIND == 1) { gpw(M.RefM2)[g] = acc[q][o]; gpw(M.RefM6)[g] = acc2[q][o]; }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// corr_volume
-// ------------------------------------------------------------------------------------------------
-// Tile = TR x TC output pixels (TR = 32 rows); NT threads; LDSB = LDS bytes one workgroup may use
-// (160 KiB / workgroups per CU).  Two shapes are built: 32x32 tiles with 512 threads, one workgroup per CU,
-// and 32x16 tiles with 256 threads, TWO workgroups per CU -- the two are independent, so while one waits for
-// its frames or drains its stores the other one computes (a single 8-wave workgroup runs its phases strictly
-// one after the other between barriers).
-template <int NW, int UB, int TC, int NT>
-struct CorrCfg {
-    static constexpr int TR = UMPA_TILE, S = 2 * NW + 1;
-    static constexpr int LDSB = (NT >= 512) ? UMPA_LDS_BUDGET : UMPA_LDS_BUDGET / 2;
-    static constexpr int QR = TR + 2 * NW, QC = TC + 2 * NW;  // q-region (tile + window halo): rows, columns
-    static constexpr int QP = QR | 1;                     // odd pitch of the transposed tiles ([column][row])
-    static constexpr int NQB = NT / QR;                   // q column-blocks handled side by side
-    static constexpr int QB = (QC + NQB - 1) / NQB;       // q columns per thread
-    static constexpr int AC = NQB * QB;                   // columns the product threads address (>= QC; the excess is never stored)
-    static constexpr int BW = QC + UB - 1;                // B columns staged
-    static constexpr int AFR = QC * QP, BFR = BW * QP;    // doubles per staged frame: packed, A then B
-    static constexpr int FRAME = AFR + BFR;
-    static constexpr int SLACK = (AC - QC) * QP;          // threads of the padding columns read this far past a frame
-    static constexpr int PPL = QC * QP;                   // one product plane
-    static constexpr int FCH_FIT = (LDSB / 8 - SLACK) / FRAME;
-    static constexpr int FCH = FCH_FIT > 5 ? 5 : FCH_FIT; // frames staged per barrier (each costs prefetch registers)
-    static constexpr int LDS_DOUBLES = (FCH * FRAME + SLACK > UB * PPL) ? FCH * FRAME + SLACK : UB * PPL;
-    static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
-    static constexpr int CB = 8;                          // outputs per filter item
-    static constexpr int HITEMS = UB * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
-    static constexpr int VITEMS = UB * (TR / CB) * TC, VROUNDS = (VITEMS + NT - 1) / NT;
-    static constexpr bool OK = FCH_FIT >= 1 && UB * PPL * 8 <= LDSB && NQB >= 1;   // frames and product planes fit into LDS
-};
-
-struct CorrArgs {
-    double* table;            // [(2ms-1)^2][rows][N1]
-    size_t slot_stride;       // rows * N1
-    int org0, org1;           // frame coordinates of output pixel (0,0) of the REGION
-    int row0, rows;           // this launch covers region rows [row0, row0+rows)
-    int N1;
-    int sigma;                // +1: B = ref sits at p+u ('sam' mode); -1: B = sam sits at p-u ('ref' mode)
-    int ntx, nty;
-    int ablate;               // diagnostics only (UMPA_HIP_ABLATE): 1 no global loads, 2 no LDS staging writes, 4 no products, 8 no filters
-};
-
-template <int NW, int UB, int TC, int NT>
-__global__ void __launch_bounds__(NT, 2)
-corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
-{
-    using C = CorrCfg<NW, UB, TC, NT>;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* lds = reinterpret_cast<double*>(smem_raw);
-
-    // One workgroup = one (tile, pass): a pass is one row offset oi and one batch of UB column offsets.
-    // The passes of a tile read the same A patch and overlapping B patches; they get consecutive slots
-    // on ONE XCD (blocks b, b+8, ... share an XCD) so that those re-reads are served by that XCD's L2
-    // instead of crossing the fabric once per pass.  Placement only affects speed.
-    const int ms = m.ms, UJ = 2 * ms - 1;
-    const int nbatch = (UJ + UB - 1) / UB, npass = UJ * nbatch;
-    const int ntiles = A.ntx * A.nty, tiles_per_xcd = (ntiles + 7) >> 3;
-    const int seq = blockIdx.x >> 3;                                  // position in this XCD's queue
-    const int lin = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;   // contiguous band of tiles per XCD
-    const int pass = seq % npass;
-    if (seq / npass >= tiles_per_xcd || lin >= ntiles) return;
-    const int tx = lin % A.ntx, ty = lin / A.ntx;
-    const int tid = threadIdx.x;
-    const int prow0 = A.row0 + ty * C::TR, pcol0 = tx * TC;           // first output pixel of the tile (region coords)
-    const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
-    const int H = gp(m.frames)->H, W = gp(m.frames)->W;
-    const int oi = pass / nbatch - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
-
-    // ---- staging slots of this thread (compile-time counts, so everything below indexes registers statically).
-    // An element is EW adjacent columns of one row: with even patch widths two doubles travel per load
-    // (global_load_dwordx4: the L1/TA path moves 16 bytes per lane at about twice the rate of 8-byte loads).
-    constexpr int EW = (C::QC % 2 == 0 && C::BW % 2 == 0) ? 2 : 1;
-    typedef double stage_t __attribute__((ext_vector_type(EW), aligned(8)));
-    constexpr int NA = (C::QR * C::QC / EW + NT - 1) / NT;            // A elements per thread and frame
-    constexpr int NB = (C::QR * C::BW / EW + NT - 1) / NT;            // B elements per thread and frame
-    int a_lds[NA], a_g[NA], b_lds[NB], b_g[NB];
-#pragma unroll
-    for (int n = 0; n < NA; n++) {
-        const int it = tid + n * NT, c = (it % (C::QC / EW)) * EW, r = it / (C::QC / EW);
-        a_lds[n] = it < C::QR * C::QC / EW ? c * C::QP + r : -1;
-        a_g[n] = min(max(fr0 + r, 0), H - 1) * W + min(max(fc0 + c, 0), W - EW);
-    }
-#pragma unroll
-    for (int n = 0; n < NB; n++) {
-        const int it = tid + n * NT, c = (it % (C::BW / EW)) * EW, r = it / (C::BW / EW);
-        b_lds[n] = it < C::QR * C::BW / EW ? c * C::QP + r : -1;
-        b_g[n] = min(max(fr0 + r + oi, 0), H - 1) * W + min(max(fc0 + c + oj0, 0), W - EW);
-    }
-    stage_t pa[C::FCH][NA], pb[C::FCH][NB];                           // frames in flight from HBM/L2
-
-    const int nchunk = (m.Na + C::FCH - 1) / C::FCH;
-    auto issue_loads = [&](int chunk) {
-        const int k0 = chunk * C::FCH;
-#pragma unroll
-        for (int f = 0; f < C::FCH; f++) {
-            if (k0 + f < m.Na) {
-                const FrameDesc fd = load_frame(m.frames, k0 + f);
-                const UMPA_GLOBAL double* __restrict__ gA = gp(A.sigma > 0 ? fd.sam : fd.ref);
-                const UMPA_GLOBAL double* __restrict__ gB = gp(A.sigma > 0 ? fd.ref : fd.sam);
-                if (A.ablate & 1) {
-#pragma unroll
-                    for (int n = 0; n < NA; n++) pa[f][n] = (stage_t)(1.0);
-#pragma unroll
-                    for (int n = 0; n < NB; n++) pb[f][n] = (stage_t)(1.0);
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NA; n++) pa[f][n] = *reinterpret_cast<const UMPA_GLOBAL stage_t*>(gA + a_g[n]);
-#pragma unroll
-                    for (int n = 0; n < NB; n++) pb[f][n] = *reinterpret_cast<const UMPA_GLOBAL stage_t*>(gB + b_g[n]);
-                }
-            }
-        }
-    };
-
-    // product-stage ownership: (qb, r), r fastest
-    const int pr = tid % C::QR, pqb = tid / C::QR;
-    const bool pactive = pqb < C::NQB;
-    double acc[C::QB][UB];
-
-#pragma unroll
-    for (int t = 0; t < C::QB; t++)
-#pragma unroll
-        for (int u = 0; u < UB; u++) acc[t][u] = 0.0;
-    issue_loads(0);
-    for (int chunk = 0; chunk < nchunk; chunk++) {
-        const int k0 = chunk * C::FCH;
-        const int nf = min(C::FCH, m.Na - k0);
-        __syncthreads();                                              // every reader of the LDS region is done
-#pragma unroll
-        for (int f = 0; f < C::FCH; f++) {
-            if (f < nf && !(A.ablate & 2)) {
-                double* la = lds + f * C::FRAME;
-                double* lb = la + C::AFR;
-#pragma unroll
-                for (int n = 0; n < NA; n++)
-                    if (a_lds[n] >= 0) {
-#pragma unroll
-                        for (int e = 0; e < EW; e++) la[a_lds[n] + e * C::QP] = EW == 2 ? pa[f][n][e] : ((const double*)&pa[f][n])[0];
-                    }
-#pragma unroll
-                for (int n = 0; n < NB; n++)
-                    if (b_lds[n] >= 0) {
-#pragma unroll
-                        for (int e = 0; e < EW; e++) lb[b_lds[n] + e * C::QP] = EW == 2 ? pb[f][n][e] : ((const double*)&pb[f][n])[0];
-                    }
-            }
-        }
-        if (chunk + 1 < nchunk) issue_loads(chunk + 1);               // flies while this chunk is consumed
-        __syncthreads();
-        if (pactive && !(A.ablate & 4)) {
-            for (int f = 0; f < nf; f++) {
-                const double* la = lds + f * C::FRAME + (pqb * C::QB) * C::QP + pr;
-                const double* lb = la + C::AFR;
-                double a[C::QB], b[C::QB + UB - 1];
-#pragma unroll
-                for (int t = 0; t < C::QB; t++) a[t] = la[t * C::QP];
-#pragma unroll
-                for (int t = 0; t < C::QB + UB - 1; t++) b[t] = lb[t * C::QP];
-#pragma unroll
-                for (int t = 0; t < C::QB; t++)
-#pragma unroll
-                    for (int u = 0; u < UB; u++) acc[t][u] = fma(a[t], b[t + u], acc[t][u]);
-            }
-        }
-    }
-    if (A.ablate & 8) return;
-    {
-        // ---- all frames of this pass are in: product planes -> LDS, H filter, V filter, store
-        const int nu = min(UB, ms - oj0);                             // offsets oj0 .. oj0+nu-1 are real
-        __syncthreads();                                              // frames consumed: the region becomes product planes
-        if (pactive) {
-#pragma unroll
-            for (int t = 0; t < C::QB; t++) {
-                const int c = pqb * C::QB + t;
-                if (c < C::QC) {
-#pragma unroll
-                    for (int u = 0; u < UB; u++) lds[u * C::PPL + c * C::QP + pr] = acc[t][u];
-                }
-            }
-        }
-        __syncthreads();
-        // H stage (along columns), results kept in registers, then written in place
-        double hres[C::HROUNDS][C::CB];
-#pragma unroll
-        for (int rd = 0; rd < C::HROUNDS; rd++) {
-            const int it = tid + rd * NT;
-            if (it < C::HITEMS) {
-                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
-                fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rd = 0; rd < C::HROUNDS; rd++) {
-            const int it = tid + rd * NT;
-            if (it < C::HITEMS) {
-                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
-                double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
-#pragma unroll
-                for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
-            }
-        }
-        __syncthreads();
-        // V stage (along rows) and store: items (u, rb, column pair), pair fastest -> coalesced table rows, and two
-        // adjacent columns per lane so that the table is written with 16-byte stores (twice the rate of 8-byte ones).
-        // Odd N1 breaks the 16-byte alignment of the rows: then the two columns are stored separately.
-        constexpr int VP = TC / 2, VITEMS2 = UB * (C::TR / C::CB) * VP, VROUNDS2 = (VITEMS2 + NT - 1) / NT;
-        typedef double out2_t __attribute__((ext_vector_type(2)));
-        const bool vec_ok = (A.N1 & 1) == 0;
-#pragma unroll
-        for (int rd = 0; rd < VROUNDS2; rd++) {
-            const int it = tid + rd * NT;
-            if (it < VITEMS2) {
-                const int cp = it % VP, rest = it / VP, rb = rest % (C::TR / C::CB), u = rest / (C::TR / C::CB);
-                if (u < nu) {
-                    const int c = 2 * cp;
-                    double out0[C::CB], out1[C::CB];
-                    fir_block<NW, C::CB>(lds + u * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out0);
-                    fir_block<NW, C::CB>(lds + u * C::PPL + (c + 1) * C::QP + rb * C::CB, 1, sep.hr, out1);
-                    const int ui = A.sigma * oi, uj = A.sigma * (oj0 + u);
-                    const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
-                    const int col = pcol0 + c;
-                    UMPA_GLOBAL double* dst = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 + rb * C::CB - A.row0) * A.N1 + col;
-#pragma unroll
-                    for (int o = 0; o < C::CB; o++) {
-                        const int row = prow0 + rb * C::CB + o;               // region row
-                        if (row < A.row0 + A.rows) {
-                            if (vec_ok && col + 1 < A.N1) {
-                                out2_t v2; v2[0] = out0[o]; v2[1] = out1[o];
-                                *reinterpret_cast<UMPA_GLOBAL out2_t*>(dst + (size_t)o * A.N1) = v2;
-                            } else {
-                                if (col < A.N1) dst[(size_t)o * A.N1] = out0[o];
-                                if (col + 1 < A.N1) dst[(size_t)o * A.N1 + 1] = out1[o];
-                            }
-                        }
-                    }
-                }
-            }
         }
     }
 }
