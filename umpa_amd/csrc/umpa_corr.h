@@ -2,9 +2,9 @@
 //   t5[u][p] = sum_k W[ s_k(.) r_k(.+u) ](p)          (the only term of Model.cpp:763-772 that couples
 // pixel and shift spatially) for all (2 max_shift - 1)^2 integer shifts u of a row chunk.
 //
-// One workgroup = one (tile, pass): a tile is TR x TC output pixels, a pass is one row offset oi and a
-// batch of UB column offsets.  Per frame k the workgroup needs the q-region (tile + window halo) of the
-// fixed-window stack A and the same region, widened by the batch, of the moving stack B.
+// One workgroup = one (tile, pass): a tile is TR x TC output pixels, a pass is UI consecutive row offsets and
+// a batch of UB column offsets.  Per frame k the workgroup needs the q-region (tile + window halo) of the
+// fixed-window stack A and the same region, widened by the offsets of the pass, of the moving stack B.
 //
 // Staging is LDS-DMA (global_load_lds_dwordx4): the frames go from L2 straight into LDS, no VGPRs, no
 // ds_write.  A wave-instruction writes 64 consecutive 16-byte pieces, the SOURCE address is per lane, so
@@ -61,23 +61,29 @@ struct CorrArgs {
 
 #define UMPA_LDS_AS __attribute__((address_space(3)))
 
-// Tile = TR x TC output pixels (TR = 32 rows); NT threads; LDSB = LDS bytes one workgroup may use
-// (160 KiB / workgroups per CU).
-template <int NW, int UB, int TC, int NT>
+// Tile = TR x TC output pixels (TR = 32 rows).  A workgroup is UI groups of NTG threads: group g works on row
+// offset oi0 + g, all groups share the staged frames (the A image, and a B image of QR + UI - 1 rows), so a pass
+// produces UI * UB planes from one staging.  WPC workgroups share a CU, so one may use LDSB = 160 KiB / WPC of
+// LDS; the planes are filtered and stored in NF rounds of PR planes (fewer planes in LDS at a time).
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
 struct CorrCfg {
+    static constexpr int NT = NTG * UI;
     static constexpr int TR = UMPA_TILE, S = 2 * NW + 1;
-    static constexpr int LDSB = (NT >= 512) ? UMPA_LDS_BUDGET : UMPA_LDS_BUDGET / 2;
+    static constexpr int LDSB = (UMPA_LDS_BUDGET / WPC) & ~15;
+    static constexpr int NPL = UI * UB;                   // planes per pass
+    static constexpr int PR = (NPL + NF - 1) / NF;        // planes per flush round
+    static constexpr int WPS = (NT / 64 * WPC + 3) / 4;   // waves per SIMD this shape is built for
     static constexpr int QR = TR + 2 * NW, QC = TC + 2 * NW;  // q-region (tile + window halo): rows, columns
+    static constexpr int QRB = QR + UI - 1;               // rows of the B image
     static constexpr int QP = QR | 1;                     // odd pitch of the transposed product planes ([column][row])
     static constexpr int PPL = QC * QP;                   // one product plane
     // product blocking: a thread owns one q row and QB consecutive columns (QB even: column pairs)
-    static constexpr int QB = (QR * ((QC + 3) / 4) <= NT) ? 4 : (QR * ((QC + 5) / 6) <= NT) ? 6 : 8;
+    static constexpr int QB = (QR * ((QC + 3) / 4) <= NTG) ? 4 : (QR * ((QC + 5) / 6) <= NTG) ? 6 : 8;
     static constexpr int NQB = (QC + QB - 1) / QB;        // column blocks
-    static constexpr int AC = NQB * QB;                   // columns the product threads address (>= QC; the excess is never stored)
     static constexpr int NBP = (QB + UB) / 2;             // B column pairs a thread reads: ceil((QB+UB-1)/2)
     static constexpr int BW = (QC + UB) & ~1;             // B columns staged, even
     static constexpr int PA = (QC / 2) | 1, PB = (BW / 2) | 1;   // 16-byte pieces per image row: odd
-    static constexpr int NPIECE = QR * (PA + PB);         // pieces of one staged frame: A image then B image
+    static constexpr int NPIECE = QR * PA + QRB * PB;     // pieces of one staged frame: A image then B image
     static constexpr int NPT = (NPIECE + NT - 1) / NT;    // LDS-DMA instructions per thread and frame
     static constexpr int SLOT = NPT * NT * 2;             // doubles per frame slot (every lane of every instruction writes)
     // the last block's threads read past the end of their image row, on the last row past the image:
@@ -86,13 +92,21 @@ struct CorrCfg {
     static constexpr int NSLOT_FIT = (LDSB / 8 - (TAIL > SLOT ? TAIL - SLOT : 0)) / SLOT;
     static constexpr int NSLOT = NSLOT_FIT > 4 ? 4 : NSLOT_FIT;               // ring depth: NSLOT-1 frames in flight
     static constexpr int RING = NSLOT * SLOT + (TAIL > SLOT ? TAIL - SLOT : 0);
-    static constexpr int LDS_DOUBLES = RING > UB * PPL ? RING : UB * PPL;
+    static constexpr int LDS_DOUBLES = RING > PR * PPL ? RING : PR * PPL;
     static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
     static constexpr int CB = 8;                          // outputs per filter item
-    static constexpr int HITEMS = UB * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
-    static constexpr bool OK = NSLOT >= 2 && UB * PPL * 8 <= LDSB && QR * NQB <= NT && (NSLOT - 1) * NPT < 64 &&
-                               LDS_DOUBLES * 8 <= LDSB;
+    static constexpr int HITEMS = PR * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
+    static constexpr bool OK = NSLOT >= 2 && PR * PPL * 8 <= LDSB && QR * NQB <= NTG && (NSLOT - 1) * NPT < 64 &&
+                               LDS_DOUBLES * 8 <= LDSB && NTG % 64 == 0 && NT <= 1024 && WPS <= 8;
 };
+
+// 16-byte store of two table entries (an `sc1` store, which makes the XCD's L2 drop the line instead of keeping it,
+// was tried so that the 2.7 GB streaming out would not evict frame patches: no difference on C2, slower on C3)
+typedef double table_pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_table16(UMPA_GLOBAL double* dst, table_pair_t v)
+{
+    *reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst) = v;
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
@@ -109,19 +123,21 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
-template <int NW, int UB, int TC, int NT>
-__global__ void __launch_bounds__(NT, 2)
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+__global__ void __launch_bounds__(NTG * UI, (NTG * UI / 64 * WPC + 3) / 4)
 corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
 {
-    using C = CorrCfg<NW, UB, TC, NT>;
+    using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>;
+    constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
 
-    // One workgroup = one (tile, pass).  The passes of a tile read the same A patch and overlapping B patches; they
-    // get consecutive slots on ONE XCD (blocks b, b+8, ... share an XCD) so that those re-reads are served by that
-    // XCD's L2 instead of crossing the fabric once per pass.  Placement only affects speed.
+    // One workgroup = one (tile, pass): a pass is UI consecutive row offsets and one batch of UB column offsets.
+    // The passes of a tile read the same A patch and overlapping B patches; they get consecutive slots on ONE XCD
+    // (blocks b, b+8, ... share an XCD) so that those re-reads are served by that XCD's L2 instead of crossing the
+    // fabric once per pass.  Placement only affects speed.
     const int ms = m.ms, UJ = 2 * ms - 1;
-    const int nbatch = (UJ + UB - 1) / UB, npass = UJ * nbatch;
+    const int nbatch = (UJ + UB - 1) / UB, npass = ((UJ + UI - 1) / UI) * nbatch;
     const int ntiles = A.ntx * A.nty, tiles_per_xcd = (ntiles + 7) >> 3;
     const int seq = blockIdx.x >> 3;                                  // position in this XCD's queue
     const int lin = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;   // contiguous band of tiles per XCD
@@ -129,10 +145,11 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
     if (seq / npass >= tiles_per_xcd || lin >= ntiles) return;
     const int tx = lin % A.ntx, ty = lin / A.ntx;
     const int tid = threadIdx.x;
+    const int grp = UI > 1 ? __builtin_amdgcn_readfirstlane(tid / NTG) : 0, gtid = tid - grp * NTG;
     const int prow0 = A.row0 + ty * C::TR, pcol0 = tx * TC;           // first output pixel of the tile (region coords)
     const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
     const int H = gp(m.frames)->H, W = gp(m.frames)->W;
-    const int oi = pass / nbatch - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
+    const int oi0 = (pass / nbatch) * UI - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
 
     // ---- LDS-DMA slots of this thread: piece p = tid + n*NT of the frame image (A rows, then B rows); its source
     // is 16 bytes = two adjacent columns of one frame row.  Pieces past the image (padding of the last instruction,
@@ -146,8 +163,8 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         bool isB = p >= C::QR * C::PA;
         if (!isB) { r = p / C::PA; c = 2 * (p % C::PA); }
         else {
-            const int q = min(p - C::QR * C::PA, C::QR * C::PB - 1);
-            r = q / C::PB + oi; c = 2 * (q % C::PB) + oj0;
+            const int q = min(p - C::QR * C::PA, C::QRB * C::PB - 1);
+            r = q / C::PB + oi0; c = 2 * (q % C::PB) + oj0;
         }
         const int gr = min(max(fr0 + r, 0), H - 1), gc = min(max(fc0 + c, 0), W - 2);
         src_off[n] = (unsigned)(gr * W + gc) * 8u;
@@ -167,9 +184,11 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         }
     };
 
-    // product-stage ownership: (qb, r), r fastest
-    const int pr = tid % C::QR, pqb = tid / C::QR;
-    const bool pactive = pqb < C::NQB;
+    // product-stage ownership inside the group: (qb, r), r fastest; a group whose row offset is past the search
+    // range (the last pass when UI does not divide 2 ms - 1) only helps with the staging and the filters
+    const int pr = gtid % C::QR, pqb = gtid / C::QR;
+    const bool gvalid = oi0 + grp <= ms - 1;
+    const bool pactive = pqb < C::NQB && gvalid;
     typedef double pair_t __attribute__((ext_vector_type(2)));
     double acc[C::QB][UB];
 #pragma unroll
@@ -190,8 +209,9 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         lds_barrier();                                                // everyone's pieces of frame k are in; slot (k-1)%NSLOT is free
         if (k + D < K && !(A.ablate & 1)) issue_frame(k + D);
         if (pactive && !(A.ablate & 4)) {
-            const pair_t* la = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT) + pr * C::PA + pqb * (C::QB / 2);
-            const pair_t* lb = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT) + C::QR * C::PA + pr * C::PB + pqb * (C::QB / 2);
+            const pair_t* img = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT);
+            const pair_t* la = img + pr * C::PA + pqb * (C::QB / 2);
+            const pair_t* lb = img + C::QR * C::PA + (pr + grp) * C::PB + pqb * (C::QB / 2);
             pair_t av[C::QB / 2], bv[C::NBP];
 #pragma unroll
             for (int t = 0; t < C::QB / 2; t++) av[t] = la[t];
@@ -204,17 +224,23 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         }
     }
     if (A.ablate & 8) return;
-    {
-        // ---- all frames of this pass are in: product planes -> LDS, H filter, V filter, store
-        const int nu = min(UB, ms - oj0);                             // offsets oj0 .. oj0+nu-1 are real
-        __syncthreads();                                              // frames consumed: the region becomes product planes
+    // ---- all frames of this pass are in.  Plane P = g*UB + u of the pass; round f puts planes [f*PR, (f+1)*PR) into
+    // LDS (transposed, [column][row]), filters them along the columns in place and along the rows on the way out.
+    const int nu = min(UB, ms - oj0);                                 // column offsets oj0 .. oj0+nu-1 are real
+    constexpr int PR = C::PR, VP = TC / 2, VITEMS2 = PR * (C::TR / C::CB) * VP, VROUNDS2 = (VITEMS2 + NT - 1) / NT;
+    const bool vec_ok = (A.N1 & 1) == 0;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        __syncthreads();                                              // frames (or the previous round's planes) consumed
         if (pactive) {
+            const int l0 = grp * UB - f * PR;                         // round-local index of this group's plane u = 0
 #pragma unroll
             for (int t = 0; t < C::QB; t++) {
                 const int c = pqb * C::QB + t;
                 if (c < C::QC) {
 #pragma unroll
-                    for (int u = 0; u < UB; u++) lds[u * C::PPL + c * C::QP + pr] = acc[t][u];
+                    for (int u = 0; u < UB; u++)
+                        if (l0 + u >= 0 && l0 + u < PR) lds[(l0 + u) * C::PPL + c * C::QP + pr] = acc[t][u];
                 }
             }
         }
@@ -241,22 +267,21 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
             }
         }
         __syncthreads();
-        // V stage (along rows) and store: items (u, rb, column pair), pair fastest -> coalesced table rows, and two
+        // V stage (along rows) and store: items (plane, rb, column pair), pair fastest -> coalesced table rows, and two
         // adjacent columns per lane so that the table is written with 16-byte stores (twice the rate of 8-byte ones).
         // Odd N1 breaks the 16-byte alignment of the rows: then the two columns are stored separately.
-        constexpr int VP = TC / 2, VITEMS2 = UB * (C::TR / C::CB) * VP, VROUNDS2 = (VITEMS2 + NT - 1) / NT;
-        const bool vec_ok = (A.N1 & 1) == 0;
 #pragma unroll
         for (int rd = 0; rd < VROUNDS2; rd++) {
             const int it = tid + rd * NT;
             if (it < VITEMS2) {
-                const int cp = it % VP, rest = it / VP, rb = rest % (C::TR / C::CB), u = rest / (C::TR / C::CB);
-                if (u < nu) {
+                const int cp = it % VP, rest = it / VP, rb = rest % (C::TR / C::CB), pl = rest / (C::TR / C::CB);
+                const int P = f * PR + pl, g = P / UB, u = P - g * UB;
+                if (P < C::NPL && u < nu && oi0 + g <= ms - 1) {
                     const int c = 2 * cp;
                     double out0[C::CB], out1[C::CB];
-                    fir_block<NW, C::CB>(lds + u * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out0);
-                    fir_block<NW, C::CB>(lds + u * C::PPL + (c + 1) * C::QP + rb * C::CB, 1, sep.hr, out1);
-                    const int ui = A.sigma * oi, uj = A.sigma * (oj0 + u);
+                    fir_block<NW, C::CB>(lds + pl * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out0);
+                    fir_block<NW, C::CB>(lds + pl * C::PPL + (c + 1) * C::QP + rb * C::CB, 1, sep.hr, out1);
+                    const int ui = A.sigma * (oi0 + g), uj = A.sigma * (oj0 + u);
                     const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
                     const int col = pcol0 + c;
                     UMPA_GLOBAL double* dst = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 + rb * C::CB - A.row0) * A.N1 + col;
@@ -266,7 +291,7 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
                         if (row < A.row0 + A.rows) {
                             if (vec_ok && col + 1 < A.N1) {
                                 pair_t v2; v2[0] = out0[o]; v2[1] = out1[o];
-                                *reinterpret_cast<UMPA_GLOBAL pair_t*>(dst + (size_t)o * A.N1) = v2;
+                                store_table16(dst + (size_t)o * A.N1, v2);
                             } else {
                                 if (col < A.N1) dst[(size_t)o * A.N1] = out0[o];
                                 if (col + 1 < A.N1) dst[(size_t)o * A.N1 + 1] = out1[o];

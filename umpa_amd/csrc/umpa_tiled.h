@@ -27,6 +27,7 @@
 #pragma once
 #include "umpa_direct.h"
 #include "umpa_corr.h"
+#include <mutex>
 
 namespace umpa {
 
@@ -376,68 +377,84 @@ inline int pick_ub(int UJ)
 {
     // batch width over the column shifts: fewest batches (each batch re-stages the frames), then least padding
     int best = 5, best_nb = 1 << 30, best_waste = 1 << 30;
-    const int cand[4] = {9, 8, 7, 5};
-    for (int q = 0; q < 4; q++) {
+    const int cand[3] = {9, 7, 5};
+    for (int q = 0; q < 3; q++) {
         const int ub = cand[q], nb = (UJ + ub - 1) / ub, w = nb * ub - UJ;
         if (nb < best_nb || (nb == best_nb && w < best_waste)) { best = ub; best_nb = nb; best_waste = w; }
     }
     return best;
 }
 
-inline int tiled_tile_cols()
+inline int tiled_corr_shape()
 {
-    const char* e = getenv("UMPA_HIP_TILE_COLS");                     // 16 or 32; default: 16 where it fits
-    return e ? atoi(e) : 16;
+    const char* e = getenv("UMPA_HIP_CORR_SHAPE");                    // tuning override, see launch_corr_shape; 0 = automatic
+    return e ? atoi(e) : 0;
 }
 
-template <int NW, int UB, int TC, int NT>
+// serialises the one-time per-device kernel attribute calls (two host threads may match on one model type)
+inline std::mutex& tiled_attr_mutex()
+{
+    static std::mutex mu;
+    return mu;
+}
+
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
 inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep, hipStream_t s)
 {
-    using C = CorrCfg<NW, UB, TC, NT>;
+    using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>;
     static bool attr_set[64] = {};                                    // the attribute is per device
     int devid = 0;
     (void)hipGetDevice(&devid);
-    if (!attr_set[devid & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB, TC, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
-        if (e != hipSuccess) return e;
-        attr_set[devid & 63] = true;
+    {
+        std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+        if (!attr_set[devid & 63]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+            if (e != hipSuccess) return e;
+            attr_set[devid & 63] = true;
+        }
     }
     A.ntx = (A.N1 + TC - 1) / TC;
     A.nty = (A.rows + C::TR - 1) / C::TR;
-    const int UJ = 2 * dev.ms - 1, npass = UJ * ((UJ + UB - 1) / UB);
+    const int UJ = 2 * dev.ms - 1, npass = ((UJ + UI - 1) / UI) * ((UJ + UB - 1) / UB);
     const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
     const int grid = 8 * tiles_per_xcd * npass;
-    hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NT>), dim3(grid), dim3(NT), C::LDS, s, dev, A, sep);
+    hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
     return hipGetLastError();
 }
 
-// 32x16 tiles / 256 threads / two workgroups per CU where the product planes fit into half the LDS, else 32x32 / 512
+// Workgroup shapes, first that fits (UMPA_HIP_CORR_SHAPE picks one by number):
+//   id: tile columns, threads per group, groups (row offsets per pass), workgroups per CU, flush rounds.
+// Measured on C2 (ms per match, round 2): 32x16 tiles / 256 threads / 2 per CU 2.12; the same with 3 per CU and two
+// flush rounds 2.05-2.18; 320 or 384 threads 2.26-2.40; two or three row offsets per pass sharing one staging
+// (512 / 768 threads, one workgroup per CU) 2.33 / 3.5-4.6 (the latter spills).  C3: 32x32 / 512 / 1 per CU 40.5-43.4,
+// 384 threads 46.1.  Only the two winners are instantiated.
+#define UMPA_CORR_SHAPES(X) X(1, 16, 256, 1, 2, 1) X(2, 32, 512, 1, 1, 1)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
 {
-    if constexpr (CorrCfg<NW, UB, 16, 256>::OK) {
-        if (tiled_tile_cols() == 16) return launch_corr<NW, UB, 16, 256>(dev, A, sep, s);
+    const int want = tiled_corr_shape();
+#define UMPA_TRY_SHAPE(id, TC, NTG, UI, WPC, NF)                                                        \
+    if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>::OK) {                                          \
+        if (want == 0 || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF>(dev, A, sep, s);  \
     }
-    return launch_corr<NW, UB, 32, 512>(dev, A, sep, s);
+    UMPA_CORR_SHAPES(UMPA_TRY_SHAPE)
+#undef UMPA_TRY_SHAPE
+    return launch_corr<NW, UB, 32, 512, 1, 1, 1>(dev, A, sep, s);
 }
 
 template <int NW>
 inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
 {
     if (ub == 9) {
-        if constexpr (CorrCfg<NW, 9, 32, 512>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s);
-        ub = 8;
-    }
-    if (ub == 8) {
-        if constexpr (CorrCfg<NW, 8, 32, 512>::OK) return launch_corr_shape<NW, 8>(dev, A, sep, s);
+        if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s);
         ub = 7;
     }
     if (ub == 7) {
-        if constexpr (CorrCfg<NW, 7, 32, 512>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s);
+        if constexpr (CorrCfg<NW, 7, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s);
         ub = 5;
     }
-    static_assert(CorrCfg<NW, 5, 32, 512>::OK, "UB=5 must always fit");
+    static_assert(CorrCfg<NW, 5, 32, 512, 1, 1, 1>::OK, "UB=5 must always fit");
     return launch_corr_shape<NW, 5>(dev, A, sep, s);
 }
 
@@ -448,11 +465,14 @@ inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& s
     static bool attr_set[64] = {};                                    // the attribute is per device
     int devid = 0;
     (void)hipGetDevice(&devid);
-    if (!attr_set[devid & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_maps_kernel<KIND, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
-        if (e != hipSuccess) return e;
-        attr_set[devid & 63] = true;
+    {
+        std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+        if (!attr_set[devid & 63]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&prep_maps_kernel<KIND, NW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+            if (e != hipSuccess) return e;
+            attr_set[devid & 63] = true;
+        }
     }
     const int ntx = (M.W - 2 * NW + C::T - 1) / C::T, nty = (M.H - 2 * NW + C::T - 1) / C::T;
     const int total = ntx * nty, grid = ((total + 7) / 8) * 8;
