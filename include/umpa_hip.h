@@ -144,6 +144,9 @@ int umpa_hip_correct_bad_pixels(const double *in, double *out, long nimg, int H,
 int umpa_hip_timing_enable(umpa_hip_model *m, int on);
 int umpa_hip_timing_collect(umpa_hip_model *m);
 int umpa_hip_timing_read(umpa_hip_model *m, int index, const char **name, double *total_ms, int *launches);
+/* fp64 fused multiply-adds executed by the collected launches of kernel `index` (counted on the host from the launch
+ * geometry; filled in for corr_volume, 0 for kernels that do not report it): the numerator of roofline.fp64_fma */
+int umpa_hip_timing_fma(umpa_hip_model *m, int index, double *fma);
 /* which path the last match_region took: 0 none, 1 direct, 2 tiled */
 int umpa_hip_last_path(umpa_hip_model *m);
 

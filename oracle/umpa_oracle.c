@@ -514,6 +514,20 @@ void umpaor_match_region(void *p, int start0, int step0, int N0, int start1, int
     }
 }
 
+/* First-touch copy for the CPU baseline of bench.py: the pages of `dst` (fresh, untouched memory) are written by
+ * the same static thread partition that a row-parallel match reads them with, so on a multi-socket host each
+ * thread's rows live on its own NUMA node instead of all on the node of the thread that generated the data. */
+void umpaor_parallel_copy(double *dst, const double *src, size_t n, int num_threads)
+{
+    const size_t chunk = 512;                      /* one page */
+    const size_t nchunk = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+    for (size_t c = 0; c < nchunk; c++) {
+        size_t a = c * chunk, b = a + chunk < n ? a + chunk : n;
+        memcpy(dst + a, src + a, (b - a) * sizeof(double));
+    }
+}
+
 int umpaor_max_threads(void)
 {
 #ifdef _OPENMP

@@ -15,6 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """UMPA_RECORD_UNCONVERGED=1: dump the unconverged-Newton counts every assert_parity call of this run saw
+    (label -> count) under gpurun_out/, to be merged into tests/golden/unconverged_observed.json."""
+    if not os.environ.get("UMPA_RECORD_UNCONVERGED"):
+        return
+    from oracle import parity
+    seen = {}
+    for label, ok, inside, unc in parity.OBSERVED:
+        seen[label] = max(seen.get(label, 0), unc)
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    tag = "gpu" if "gpu" in (session.config.getoption("-m") or "") and "not gpu" not in (session.config.getoption("-m") or "") else "cpu"
+    json.dump(seen, open(os.path.join(out, "unconverged_%s.json" % tag), "w"), indent=0, sort_keys=True)
+
+
 # ----------------------------------------------------------------------------- golden cases
 
 class Case:
@@ -89,88 +104,8 @@ ALL_CASES = ["A_small", "B_walks", "C_mask", "C_mask_ones", "D_stepping", "E_dfk
 
 
 # ----------------------------------------------------------------------------- the parity bar
-
-RTOL = 1e-5          # BASELINE.json north_star: <= 1e-5 relative on the float maps
-
-
-def assert_parity(got, want, max_shift, label="", allow_illposed=0.02, subpx=-1, f_on_failed=True):
-    """The parity definition of SURVEY.md section 8(c):
-      (i)   err, Ncalls (and, for sub_pixel_mode 0, the integer minimum) bit-exact on all pixels;
-      (ii)  T, df <= 1e-5 relative on err == 1 pixels;
-      (iii) dx, dy: |d| <= 1e-5 max(1, |ref|), f <= 1e-5 relative, on err == 1 pixels whose reference
-            sub-pixel result stayed inside the search box.  A pixel may miss the bar only if the
-            reference's own Newton iteration is not converged there (`newton_unconverged`: the
-            iteration stops at a step of 1e-4 px or after 21 steps, Optim.cpp:91,123, so where it
-            converges slowly the answer depends on rounding -- two builds of the reference itself
-            differ on such pixels, SURVEY.md section 7); those pixels are counted and bounded;
-      (iv)  err == 0 pixels: dx, dy bit-exact; T, df, f <= 1e-5 relative.  `f` is excluded where the walk
-            failed before its first move: the reference then returns an uninitialised stack variable
-            (`T D;` in Model.cpp:566/:927 is only assigned at Optim.cpp:423 or :399-404); this repo's
-            implementations return 0.0 there."""
-    assert got["err"].shape == want["err"].shape, label
-    assert got["err"].dtype == np.int32
-    np.testing.assert_array_equal(got["err"], want["err"], err_msg=label + " err")
-    if "debug_Ncalls" in got and "debug_Ncalls" in want:
-        np.testing.assert_array_equal(got["debug_Ncalls"], want["debug_Ncalls"], err_msg=label + " Ncalls")
-    ok = want["err"] == 1
-    bad = ~ok
-    n1 = want["debug_Ncalls"] == 1 if "debug_Ncalls" in want else np.zeros_like(ok)
-
-    def rel(a, b):
-        return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
-
-    for k in ("T", "df"):
-        if k in want:
-            assert k in got, label + " missing " + k
-            r = rel(got[k], want[k])
-            assert not np.any(r[ok] > RTOL), "%s %s: max rel %.3e on ok pixels" % (label, k, r[ok].max())
-            if bad.any():
-                sel = bad & np.isfinite(want[k])
-                assert not np.any(r[sel] > RTOL), "%s %s: max rel %.3e on failed pixels" % (label, k, r[sel].max())
-    inside = ok & (np.abs(want["dx"]) <= max_shift) & (np.abs(want["dy"]) <= max_shift)
-    miss = np.zeros_like(ok)
-    for k in ("dx", "dy"):
-        d = np.abs(got[k] - want[k]) / np.maximum(1.0, np.abs(want[k]))
-        miss |= inside & ~(d <= RTOL)
-    miss |= inside & ~(rel(got["f"], want["f"]) <= RTOL)
-    unconverged = 0
-    if miss.any():
-        assert subpx != 0, "%s: %d pixels differ with the sub-pixel fit switched off" % (label, miss.sum())
-        assert "debug_a" in got and "debug_d" in got, \
-            "%s: %d in-box ok pixels miss the 1e-5 bar (no debug arrays to classify them)" % (label, miss.sum())
-        for (xi, xj) in np.argwhere(miss):
-            if not newton_unconverged(got["debug_a"][xi, xj], got["debug_d"][xi, xj]):
-                raise AssertionError("%s: pixel (%d,%d) misses the 1e-5 bar although the reference's Newton "
-                                     "iteration is converged there: dx %r vs %r, dy %r vs %r, f %r vs %r" % (
-                                         label, xi, xj, got["dx"][xi, xj], want["dx"][xi, xj], got["dy"][xi, xj],
-                                         want["dy"][xi, xj], got["f"][xi, xj], want["f"][xi, xj]))
-            unconverged += 1
-        assert unconverged <= max(4, allow_illposed * ok.sum()), \
-            "%s: %d unconverged-Newton pixels of %d differ; too many to wave through" % (label, unconverged, ok.sum())
-    if bad.any():
-        for k in ("dx", "dy"):
-            np.testing.assert_array_equal(got[k][bad], want[k][bad], err_msg=label + " " + k + " on failed pixels")
-        sel = bad & ~n1 & np.isfinite(want["f"]) & (got["f"] != 0.0) & bool(f_on_failed)
-        r = rel(got["f"], want["f"])
-        assert not np.any(r[sel] > RTOL), "%s f: max rel %.3e on failed pixels" % (label, r[sel].max())
-    return dict(ok=int(ok.sum()), inside=int(inside.sum()), unconverged=int(unconverged))
-
-
-def newton_unconverged(a16, memo25):
-    """True where the reference's spmin stopped before converging on this 4x4 neighbourhood: restarting the
-    iteration from its own answer still moves the position by more than 1e-6 px."""
-    import ctypes as C
-    from oracle import cpu_model
-    lib = cpu_model.native("port")
-    dp = C.POINTER(C.c_double)
-    a = np.ascontiguousarray(a16, dtype=np.float64)
-    ip = 1 if memo25[17] < memo25[7] else 0          # Optim.cpp:344-345
-    jp = 1 if memo25[13] < memo25[11] else 0
-    p1 = np.array([1.0 - ip, 1.0 - jp])
-    lib.spmin(a.ctypes.data_as(dp), p1.ctypes.data_as(dp))
-    p2 = p1.copy()
-    lib.spmin(a.ctypes.data_as(dp), p2.ctypes.data_as(dp))
-    return bool(np.any(~(np.abs(p2 - p1) <= 1e-6 * np.maximum(1.0, np.abs(p1)))))
+# (lives in oracle/parity.py so that bench.py's cpu_baseline leg and __graft_entry__.smoke() apply the same rules)
+from oracle.parity import RTOL, assert_parity, newton_unconverged  # noqa: E402,F401
 
 
 @pytest.fixture(scope="session")

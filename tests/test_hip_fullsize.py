@@ -85,3 +85,66 @@ def test_roi_and_step_are_slices_of_the_full_result(stack):
     np.testing.assert_array_equal(part["err"], full["err"][3::97, 5::53])
     ok = part["err"] == 1
     np.testing.assert_allclose(part["T"][ok], full["T"][3::97, 5::53][ok], rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# the other BASELINE configurations at (or near) their sizes, against the CPU oracle on row samples
+# ------------------------------------------------------------------------------------------------
+def _oracle_rows(port_ns, cls, sam, ref, Nw, ms, rows):
+    m = getattr(port_ns, cls)(sam, ref, window_size=Nw, max_shift=ms)
+    m.debug = True
+    N1 = m.extent[1]
+    return {r0: m.match(ROI=((r0, r1, 1), (0, N1, 1)), quiet=True) for r0, r1 in rows}
+
+
+def test_C4_slab_full_width_against_the_oracle(port_ns):
+    """One rank's slab of BASELINE config C4 (8192 columns, 1022 output rows + halo, 10 frames, Nw=5, max_shift=5):
+    the whole slab on the GPU, three row bands of it on the CPU oracle."""
+    from conftest import assert_parity
+    from umpa_amd import model
+    from umpa_amd.synth import make_block
+    Nw, ms, K, W = 5, 5, 10, 8192
+    P = Nw + ms
+    sam, ref = make_block((3 * 1022, 4 * 1022 + 2 * P), 8192, W, K, ms, seed=300)      # rank 3's rows of the C4 image
+    m = model.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms)
+    m.debug = True
+    N0, N1 = m.extent
+    assert (N0, N1) == (1022, 8172)
+    bands = [(0, 3), (509, 512), (1019, 1022)]
+    want = _oracle_rows(port_ns, "UMPAModelDF", sam, ref, Nw, ms, bands)
+    for r0, r1 in bands:                                            # the GPU matches each band as an ROI of the slab model...
+        got = m.match(ROI=((r0, r1, 1), (0, N1, 1)), quiet=True)
+        assert_parity(got, want[r0], ms, "C4 slab rows %d-%d" % (r0, r1))
+    m.debug = False                                                 # ...and the whole slab once: its bands must be those
+    m.ROI = None                                                    # (match(ROI=...) leaves the ROI set, as in the reference)
+    full = m.match(quiet=True)
+    assert full["T"].shape == (1022, 8172)
+    for r0, r1 in bands:
+        np.testing.assert_array_equal(full["err"][r0:r1], want[r0]["err"])
+        ok = want[r0]["err"] == 1
+        np.testing.assert_allclose(full["T"][r0:r1][ok], want[r0]["T"][ok], rtol=1e-5)
+
+
+def test_C3_parameters_at_1536_multi_chunk_table(port_ns, monkeypatch):
+    """BASELINE config C3's parameters (20 frames, Nw=7, max_shift=8) on 1536 x 1536 with the default table budget
+    (4 GiB: 225 planes of 1506 columns give 1568-row chunks, so a 1506-row region is one chunk) and with a 1 GiB budget
+    (four chunks): same maps, and row bands of them against the CPU oracle."""
+    from conftest import assert_parity
+    from umpa_amd import model
+    from umpa_amd.synth import make_stack
+    Nw, ms, K, n = 7, 8, 20, 1536
+    sam, ref, _ = make_stack(n, n, K, ms, df=True, seed=7, order=1)
+    m = model.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms)
+    m.debug = True
+    N0, N1 = m.extent
+    a = m.match(quiet=True)
+    assert m._lib.last_path(m._handle) == 2
+    monkeypatch.setenv("UMPA_HIP_TABLE_MB", "1024")
+    b = m.match(quiet=True)
+    for k in ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    bands = [(0, 2), (700, 702), (N0 - 2, N0)]
+    want = _oracle_rows(port_ns, "UMPAModelDF", sam, ref, Nw, ms, bands)
+    for r0, r1 in bands:
+        got = {k: (v[r0:r1] if isinstance(v, np.ndarray) and v.shape[:1] == (N0,) else v) for k, v in a.items()}
+        assert_parity(got, want[r0], ms, "C3 params 1536 rows %d-%d" % (r0, r1))

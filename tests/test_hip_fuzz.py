@@ -64,4 +64,4 @@ def test_random_configuration(namespaces, c):
     if c["dxdy"] is not None:
         kw["dxdy"] = c["dxdy"]
     got, want = g.match(**kw), o.match(**kw)
-    assert_parity(got, want, c["ms"], str(c), subpx=c["subpx"], allow_illposed=0.05)
+    assert_parity(got, want, c["ms"], str(c), subpx=c["subpx"])

@@ -54,6 +54,29 @@ def _worker(rank, world, port, tmp):
         np.testing.assert_array_equal(padded.numpy(), sam[:, lo: own1 + (halo if rank < world - 1 else 0)])
         assert lo <= a and own1 + (halo if rank < world - 1 else 0) >= b      # slab + halo is covered
 
+        # (2b) the persistent-buffer form bench.py --gpus N uses: input rows split in nearly equal blocks, the halo
+        # rows of both stacks fetched in one send/recv group straight into the model's frame buffer, result slabs
+        # gathered as padded tensors
+        H = sam.shape[1]
+        st_s = sharding.RowShardedStack(sam.shape[0], H, sam.shape[2], P, world, rank)
+        st_r = sharding.RowShardedStack(ref.shape[0], H, ref.shape[2], P, world, rank)
+        o0, o1 = st_s.own[rank]
+        st_s.buf.fill_(float("nan")); st_r.buf.fill_(float("nan"))
+        st_s.own_rows().copy_(torch.from_numpy(sam[:, o0:o1]))
+        st_r.own_rows().copy_(torch.from_numpy(ref[:, o0:o1]))
+        sharding.exchange_halos([st_s, st_r])
+        na, nb = st_s.need[rank]
+        assert (na, nb) == (a, b)
+        np.testing.assert_array_equal(torch.stack(st_s.frames()).numpy(), sam[:, a:b])
+        np.testing.assert_array_equal(torch.stack(st_r.frames()).numpy(), ref[:, a:b])
+        assert st_s.halo_bytes() == ((o0 - na) + (nb - o1)) * sam.shape[2] * sam.shape[0] * 8
+        sub = cpu_model.port.UMPAModelDF([f.numpy() for f in st_s.frames()], [f.numpy() for f in st_r.frames()],
+                                         window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
+        biggest = max(q1 - q0 for q0, q1 in st_s.out)
+        pad = torch.zeros((biggest,) + sub["T"].shape[1:], dtype=torch.float64)
+        pad[: r1 - r0] = torch.from_numpy(sub["T"])
+        whole_T = sharding.gather_slabs(pad, n_out, dst=0)
+
         # (3) all_gather variant
         every = sharding.gather_rows({"err": res["err"]}, n_out, dst=None)
         assert every["err"].shape[0] == n_out
@@ -63,9 +86,10 @@ def _worker(rank, world, port, tmp):
             for k in ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls"):
                 np.testing.assert_array_equal(whole[k], full[k], err_msg=k)
             np.testing.assert_array_equal(every["err"], full["err"])
+            np.testing.assert_array_equal(whole_T.numpy(), full["T"])
             open(os.path.join(tmp, "ok_%d" % world), "w").write("ok")
         else:
-            assert whole is None
+            assert whole is None and whole_T is None
     finally:
         dist.destroy_process_group()
 
@@ -147,3 +171,97 @@ def test_row_sharding_on_the_gpu(tmp_path):
     port = _free_port()
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "gpu_ok").exists()
+
+
+def _gpu_sharded_worker(rank, world, port, tmp, backend):
+    """The path of bench.py --gpus N at a small size: the frames live row-sharded on the device(s) in persistent
+    buffers, the halo rows travel between the ranks, the model borrows the device rows, the result slabs are gathered
+    on rank 0 -- and must equal the unsharded HIP result bit for bit."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from umpa_amd import model, sharding
+    from umpa_amd.synth import make_stack
+
+    local = rank % torch.cuda.device_count()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Nw, ms = 3, 4
+        P = Nw + ms
+        sam, ref, _ = make_stack(190, 210, 4, ms, df=True, seed=21, amplitude=2.0)
+        K, H, W = sam.shape
+        n_out, N1 = H - 2 * P, W - 2 * P
+        st_s = sharding.RowShardedStack(K, H, W, P, world, rank, device=dev)
+        st_r = sharding.RowShardedStack(K, H, W, P, world, rank, device=dev)
+        o0, o1 = st_s.own[rank]
+        st_s.buf.fill_(float("nan")); st_r.buf.fill_(float("nan"))
+        st_s.own_rows().copy_(torch.from_numpy(sam[:, o0:o1]))
+        st_r.own_rows().copy_(torch.from_numpy(ref[:, o0:o1]))
+        sharding.exchange_halos([st_s, st_r])
+        m = model.UMPAModelDF(st_s.frames(), st_r.frames(), window_size=Nw, max_shift=ms, device=local)
+        res = m.match(quiet=True)
+        r0, r1 = st_s.out[rank]
+        assert res["T"].shape == (r1 - r0, N1)
+        biggest = max(b - a for a, b in st_s.out)
+        whole = {}
+        for k in ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls"):
+            pad = torch.zeros((biggest, N1), dtype=torch.from_numpy(res[k]).dtype, device=dev)
+            pad[: r1 - r0] = torch.from_numpy(res[k]).to(dev)
+            got = sharding.gather_slabs(pad, n_out, dst=0)
+            if rank == 0:
+                whole[k] = got.cpu().numpy()
+        if rank == 0:
+            full = model.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms, device=local).match(quiet=True)
+            for k in whole:
+                np.testing.assert_array_equal(whole[k], full[k], err_msg=k)
+            assert full["err"].mean() > 0.5
+            open(os.path.join(tmp, "sharded_ok_" + backend), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_device_sharded_frames_on_one_gpu(tmp_path):
+    """two ranks share the one GPU of the test box; the halo and the gather travel over gloo (staged through the host)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_sharded_worker, args=(2, port, str(tmp_path), "gloo"), nprocs=2, join=True)
+    assert (tmp_path / "sharded_ok_gloo").exists()
+
+
+@pytest.mark.gpu
+def test_device_sharded_frames_over_rccl(tmp_path):
+    """one rank per GPU, halo exchange and gather over RCCL: needs at least two GPUs (the driver's 8-GPU node)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the RCCL variant needs two")
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_sharded_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    assert (tmp_path / "sharded_ok_nccl").exists()
+
+
+@pytest.mark.gpu
+def test_bench_sharded_leg_rehearsal(tmp_path):
+    """bench.py --gpus 2 end to end at a reduced size (two ranks on one GPU, gloo): the JSON line of the C4 leg"""
+    import json
+    import subprocess
+    env = dict(os.environ, UMPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--rows", "128", "--cols", "512"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rccl_world_size"] == 2
+    assert d["config"]["output_pixels_total"] == (256 - 20) * (512 - 20)
+    for k in ("halo_ms", "match_ms", "gather_ms"):
+        assert d["config"][k] > 0
+    assert d["value"] > 0 and d["roofline"]["kernel"] in ("corr_volume", "replay_walk", "prep_maps")

@@ -26,7 +26,7 @@ _dpp = C.POINTER(_dp)
 HIP_SYMBOLS = [
     "device_count", "last_error", "version", "create", "destroy", "set_window", "set_subpx",
     "set_reference_shift", "coverage", "coverage_region", "cost", "min", "match_region",
-    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "last_path",
+    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path",
     "update_frames", "correct_bad_pixels",
 ]
 
@@ -75,6 +75,7 @@ class Native:
             f("timing_enable", C.c_int, [C.c_void_p, C.c_int])
             f("timing_collect", C.c_int, [C.c_void_p])
             f("timing_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), _dp, _ip])
+            f("timing_fma", C.c_int, [C.c_void_p, C.c_int, _dp])
             f("last_path", C.c_int, [C.c_void_p])
             f("update_frames", C.c_int, [C.c_void_p, _dpp, _dpp])
             f("correct_bad_pixels", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,

@@ -56,7 +56,7 @@ struct DevBuf {                       // grow-only device scratch
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct TimedLaunch { int name; hipEvent_t t0, t1; };
+struct TimedLaunch { int name; hipEvent_t t0, t1; double fma; };
 
 } // namespace
 
@@ -81,6 +81,7 @@ struct umpa_hip_model {
     std::vector<std::string> tnames;
     std::vector<double> tms;
     std::vector<int> tcount;
+    std::vector<double> tfma;
 
     ModelDev dev() const
     {
@@ -109,7 +110,7 @@ struct ScopedTimer {                   // brackets a launch with events when tim
     ScopedTimer(umpa_hip_model* m_, hipStream_t s_, int name) : m(m_), s(s_), on(m_->timing)
     {
         if (!on) return;
-        tl.name = name; tl.t0 = get_event(m); tl.t1 = get_event(m);
+        tl.name = name; tl.t0 = get_event(m); tl.t1 = get_event(m); tl.fma = 0.0;
         if (!tl.t0 || !tl.t1) { on = false; return; }
         (void)hipEventRecord(tl.t0, s);
     }
@@ -247,13 +248,12 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s)
         return fail(UMPA_HIP_E_UNSUPPORTED, "tiled path does not cover this model/region");
     if (can_tile && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
         TiledTimers tt;
+        tt.get = [m]() { return get_event(m); };
         int rc = tiled_match(m->tiled, m->dev(), m->kind, m->dims[0], m->dims[1], A, s,
                              m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0);
         if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
         if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
-        if (m->timing) {
-            for (int q = 0; q < tt.n; q++) { TimedLaunch tl; tl.name = tt.name[q]; tl.t0 = tt.t0[q]; tl.t1 = tt.t1[q]; m->launches.push_back(tl); }
-        }
+        for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; m->launches.push_back(tl); }
         m->last_path = 2;
         return 0;
     }
@@ -651,15 +651,15 @@ int umpa_hip_timing_collect(umpa_hip_model* m)
 {
     if (!m) return fail(UMPA_HIP_E_ARG, "null model");
     (void)hipSetDevice(m->device);
-    m->tnames.clear(); m->tms.clear(); m->tcount.clear();
+    m->tnames.clear(); m->tms.clear(); m->tcount.clear(); m->tfma.clear();
     for (auto& l : m->launches) {
         float ms = 0.f;
         if (hipEventSynchronize(l.t1) == hipSuccess && hipEventElapsedTime(&ms, l.t0, l.t1) == hipSuccess) {
             const char* nm = KERNEL_NAMES[l.name];
             size_t q = 0;
             for (; q < m->tnames.size(); q++) if (m->tnames[q] == nm) break;
-            if (q == m->tnames.size()) { m->tnames.push_back(nm); m->tms.push_back(0.0); m->tcount.push_back(0); }
-            m->tms[q] += ms; m->tcount[q] += 1;
+            if (q == m->tnames.size()) { m->tnames.push_back(nm); m->tms.push_back(0.0); m->tcount.push_back(0); m->tfma.push_back(0.0); }
+            m->tms[q] += ms; m->tcount[q] += 1; m->tfma[q] += l.fma;
         }
         m->event_pool.push_back(l.t0); m->event_pool.push_back(l.t1);
     }
@@ -673,6 +673,13 @@ int umpa_hip_timing_read(umpa_hip_model* m, int index, const char** name, double
     if (name) *name = m->tnames[index].c_str();
     if (total_ms) *total_ms = m->tms[index];
     if (launches) *launches = m->tcount[index];
+    return 0;
+}
+
+int umpa_hip_timing_fma(umpa_hip_model* m, int index, double* fma)
+{
+    if (!m || !fma || index < 0 || index >= (int)m->tfma.size()) return fail(UMPA_HIP_E_ARG, "bad timing index");
+    *fma = m->tfma[index];
     return 0;
 }
 

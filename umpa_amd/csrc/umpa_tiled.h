@@ -28,6 +28,8 @@
 #include "umpa_direct.h"
 #include "umpa_corr.h"
 #include <mutex>
+#include <vector>
+#include <functional>
 
 namespace umpa {
 
@@ -337,7 +339,13 @@ struct TiledState {
     size_t ref_plane = 0;
 };
 
-struct TiledTimers { int n = 0; int name[64]; hipEvent_t t0[64], t1[64]; };
+// one entry per timed launch of a tiled match; the events come from the model's pool (`get`), so nothing is
+// created per launch and a match split into any number of row chunks is recorded completely
+struct TiledTimers {
+    struct Entry { int name; hipEvent_t t0, t1; double fma; };
+    std::vector<Entry> entries;
+    std::function<hipEvent_t()> get;
+};
 
 inline bool tiled_supported(int Nw, int ms, int Na)
 {
@@ -399,7 +407,7 @@ inline std::mutex& tiled_attr_mutex()
 }
 
 template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
-inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep, hipStream_t s)
+inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep, hipStream_t s, double* fma)
 {
     using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>;
     static bool attr_set[64] = {};                                    // the attribute is per device
@@ -419,6 +427,13 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
     const int UJ = 2 * dev.ms - 1, npass = ((UJ + UI - 1) / UI) * ((UJ + UB - 1) / UB);
     const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
     const int grid = 8 * tiles_per_xcd * npass;
+    if (fma) {
+        // fp64 FMAs this launch executes: per (tile, pass) the products of the active threads over all frames, the
+        // column filter on QR rows and the row filter on the tile, for every plane of the pass (roofline accounting)
+        const double per_pass = (double)C::QR * C::NQB * C::QB * UB * UI * dev.Na +
+                                (double)C::NPL * C::QR * TC * C::S + (double)C::NPL * C::TR * TC * C::S;
+        *fma = per_pass * (double)A.ntx * A.nty * npass;
+    }
     hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
     return hipGetLastError();
 }
@@ -431,31 +446,31 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // 384 threads 46.1.  Only the two winners are instantiated.
 #define UMPA_CORR_SHAPES(X) X(1, 16, 256, 1, 2, 1) X(2, 32, 512, 1, 1, 1)
 template <int NW, int UB>
-inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
+inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
 {
     const int want = tiled_corr_shape();
 #define UMPA_TRY_SHAPE(id, TC, NTG, UI, WPC, NF)                                                        \
     if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>::OK) {                                          \
-        if (want == 0 || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF>(dev, A, sep, s);  \
+        if (want == 0 || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF>(dev, A, sep, s, fma);  \
     }
     UMPA_CORR_SHAPES(UMPA_TRY_SHAPE)
 #undef UMPA_TRY_SHAPE
-    return launch_corr<NW, UB, 32, 512, 1, 1, 1>(dev, A, sep, s);
+    return launch_corr<NW, UB, 32, 512, 1, 1, 1>(dev, A, sep, s, fma);
 }
 
 template <int NW>
-inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s)
+inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
 {
     if (ub == 9) {
-        if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s);
+        if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s, fma);
         ub = 7;
     }
     if (ub == 7) {
-        if constexpr (CorrCfg<NW, 7, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s);
+        if constexpr (CorrCfg<NW, 7, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s, fma);
         ub = 5;
     }
     static_assert(CorrCfg<NW, 5, 32, 512, 1, 1, 1>::OK, "UB=5 must always fit");
-    return launch_corr_shape<NW, 5>(dev, A, sep, s);
+    return launch_corr_shape<NW, 5>(dev, A, sep, s, fma);
 }
 
 template <int KIND, int NW>
@@ -548,8 +563,22 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         st.table_cap = table_need;
     }
 
-    auto tic = [&](int name) { if (tt && tt->n < 64) { tt->name[tt->n] = name; (void)hipEventCreate(&tt->t0[tt->n]); (void)hipEventCreate(&tt->t1[tt->n]); (void)hipEventRecord(tt->t0[tt->n], s); } };
-    auto toc = [&]() { if (tt && tt->n < 64) { (void)hipEventRecord(tt->t1[tt->n], s); tt->n++; } };
+    bool timing_open = false;
+    auto tic = [&](int name) {
+        timing_open = false;
+        if (!tt) return;
+        TiledTimers::Entry en = {name, tt->get(), tt->get(), 0.0};
+        if (!en.t0 || !en.t1) return;
+        (void)hipEventRecord(en.t0, s);
+        tt->entries.push_back(en);
+        timing_open = true;
+    };
+    auto toc = [&](double fma = 0.0) {
+        if (!timing_open) return;
+        tt->entries.back().fma = fma;
+        (void)hipEventRecord(tt->entries.back().t1, s);
+        timing_open = false;
+    };
 
     hipError_t e = hipErrorInvalidValue;
     tic(2);
@@ -572,9 +601,10 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         { const char* ab = getenv("UMPA_HIP_ABLATE"); CA.ablate = ab ? atoi(ab) : 0; }
         CA.ntx = CA.nty = 0;                                          // set by launch_corr for the tile shape it picks
         e = hipErrorInvalidValue;
+        double corr_fma = 0.0;
         tic(3);
-        UMPA_NW_SWITCH(Nw, (e = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s)))
-        toc();
+        UMPA_NW_SWITCH(Nw, (e = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s, &corr_fma)))
+        toc(corr_fma);
         if (e != hipSuccess) return (int)e;
 
         // output rows whose dense row lies in [drow0, drow0 + drows)

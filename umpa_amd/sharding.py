@@ -21,7 +21,8 @@ Two input situations are covered:
 """
 import numpy as np
 
-__all__ = ["slab_bounds", "input_rows", "match_rows", "exchange_halo", "gather_rows"]
+__all__ = ["slab_bounds", "input_rows", "match_rows", "exchange_halo", "gather_rows",
+           "RowShardedStack", "exchange_halos", "gather_slabs"]
 
 
 def slab_bounds(n_rows, world, rank):
@@ -115,3 +116,116 @@ def gather_rows(local, n_rows, dst=0, group=None, device=None):
         if bufs is not None:
             out[key] = np.concatenate([bufs[g][: sizes[g][1] - sizes[g][0]].cpu().numpy() for g in range(world)], axis=0)
     return out if (dst is None or rank == dst) else None
+
+
+# ------------------------------------------------------------------------------------------------
+# Frames that live row-sharded on the devices (BASELINE config C4; bench.py --gpus N)
+# ------------------------------------------------------------------------------------------------
+
+class RowShardedStack:
+    """This rank's part of a ``[K, H, W]`` stack whose INPUT rows are split over the ranks in contiguous,
+    nearly equal blocks (``slab_bounds(H, world, rank)``: the rows an upstream producer on this GPU writes).
+
+    The rank matches the OUTPUT rows ``slab_bounds(H - 2*padding, world, rank)`` and needs the input rows
+    ``input_rows(...)`` for them: its own block plus a few boundary rows of the previous / next rank.  One
+    persistent buffer holds exactly the rows [lo, hi) = own block + halo; ``own_rows()`` is where the producer
+    writes, ``exchange_halos`` fills the rest from the neighbours, ``frames()`` are the K contiguous 2-D views
+    a model borrows (``UMPA_HIP_F_DEVICE_FRAMES``).
+    """
+
+    def __init__(self, K, H, W, padding, world, rank, device=None, dtype=None):
+        import torch
+        self.K, self.H, self.W, self.padding, self.world, self.rank = int(K), int(H), int(W), int(padding), int(world), int(rank)
+        n_out = self.H - 2 * self.padding
+        if n_out < world:
+            raise ValueError("fewer output rows than ranks")
+        self.own = [slab_bounds(self.H, world, g) for g in range(world)]
+        self.need = [input_rows(n_out, self.padding, world, g) for g in range(world)]
+        self.out = [slab_bounds(n_out, world, g) for g in range(world)]
+        for g in range(world):
+            (o0, o1), (a, b) = self.own[g], self.need[g]
+            # the halo of a rank comes from its direct neighbours only
+            if a < o0 and (g == 0 or a < self.own[g - 1][0]):
+                raise ValueError("rank %d needs rows above its upper neighbour's block" % g)
+            if b > o1 and (g == world - 1 or b > self.own[g + 1][1]):
+                raise ValueError("rank %d needs rows below its lower neighbour's block" % g)
+        (o0, o1), (a, b) = self.own[rank], self.need[rank]
+        self.lo, self.hi = min(o0, a), max(o1, b)
+        self.buf = torch.empty((self.K, self.hi - self.lo, self.W), dtype=dtype or torch.float64, device=device)
+
+    # rows [r0, r1) of the whole image as a view of the buffer
+    def rows(self, r0, r1):
+        assert self.lo <= r0 <= r1 <= self.hi
+        return self.buf[:, r0 - self.lo: r1 - self.lo]
+
+    def own_rows(self):
+        return self.rows(*self.own[self.rank])
+
+    def frames(self):
+        a, b = self.need[self.rank]
+        return [self.buf[k, a - self.lo: b - self.lo] for k in range(self.K)]
+
+    def halo_plan(self):
+        """[(peer, 'send'|'recv', r0, r1)]: rows this rank sends to / receives from its neighbours."""
+        g, plan = self.rank, []
+        (o0, o1), (a, b) = self.own[g], self.need[g]
+        if a < o0:
+            plan.append((g - 1, "recv", a, o0))
+        if b > o1:
+            plan.append((g + 1, "recv", o1, b))
+        if g > 0 and self.need[g - 1][1] > self.own[g - 1][1]:          # the upper neighbour's bottom deficit
+            plan.append((g - 1, "send", self.own[g - 1][1], self.need[g - 1][1]))
+        if g < self.world - 1 and self.need[g + 1][0] < self.own[g + 1][0]:
+            plan.append((g + 1, "send", self.need[g + 1][0], self.own[g + 1][0]))
+        return plan
+
+    def halo_bytes(self):
+        return sum((r1 - r0) * self.W * self.K * self.buf.element_size() for _, kind, r0, r1 in self.halo_plan() if kind == "recv")
+
+
+def exchange_halos(stacks, group=None):
+    """Fill the halo rows of every ``RowShardedStack`` in ``stacks`` from the neighbour ranks: all sends and
+    receives of all stacks go into ONE ``batch_isend_irecv`` group (``ncclSend``/``ncclRecv`` under RCCL, one
+    xGMI link per neighbour and direction).  With the gloo backend the rows are staged through the host."""
+    import torch
+    import torch.distributed as dist
+    via_host = dist.get_backend(group) != "nccl"
+    ops, landing = [], []
+    for st in stacks:
+        for peer, kind, r0, r1 in st.halo_plan():
+            view = st.rows(r0, r1)
+            if kind == "send":
+                t = view.contiguous()
+                ops.append(dist.P2POp(dist.isend, t.cpu() if via_host else t, peer, group))
+            else:
+                t = torch.empty(view.shape, dtype=view.dtype, device="cpu" if via_host else view.device)
+                ops.append(dist.P2POp(dist.irecv, t, peer, group))
+                landing.append((view, t))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for view, t in landing:
+        view.copy_(t)
+
+
+def gather_slabs(local, n_rows, dst=0, group=None, out=None):
+    """Gather one padded result tensor per rank on ``dst``: ``local`` is ``[biggest, ...]`` (this rank's slab in its
+    first rows, ``biggest`` = the largest slab) on the device the backend moves (HIP for nccl).  Returns the
+    whole ``[n_rows, ...]`` tensor on ``dst`` (written into ``out`` if given), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [slab_bounds(n_rows, world, g) for g in range(world)]
+    biggest = max(b - a for a, b in sizes)
+    assert local.shape[0] == biggest, "pad the local slab to the largest slab (%d rows)" % biggest
+    via_host = dist.get_backend(group) != "nccl" and local.is_cuda
+    send = local.cpu() if via_host else local
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    if out is None:
+        out = torch.empty((n_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for g, (a, b) in enumerate(sizes):
+        out[a:b].copy_(bufs[g][: b - a])
+    return out

@@ -85,3 +85,34 @@ def make_stack_fast(H, W, K, max_shift, df=True, seed=0, T0=0.8, D0=0.7, noise=0
     """
     return make_stack(H, W, K, max_shift, df=df, seed=seed, T0=T0, D0=D0, noise=noise,
                       amplitude=amplitude, order=1)
+
+
+def make_block(rows, H_full, W, K, max_shift, df=True, seed=0, T0=0.8, D0=0.7, noise=0.005,
+               amplitude=None, order=1):
+    """Rows ``rows = (a, b)`` of a virtual ``H_full x W`` stack, for a rank that owns only that row block
+    (bench.py's multi-GPU leg: BASELINE config C4 is 8 such blocks of 1024 rows).
+
+    The displacement field is the whole image's; the speckle of a block is drawn from the block's own seed
+    (with a margin so that the warp has rows to sample from), so the image is the concatenation of the blocks.
+    Returns ``(sam, ref)``, float64 ``[K, b - a, W]``.
+    """
+    from scipy.ndimage import map_coordinates
+    a, b = int(rows[0]), int(rows[1])
+    if amplitude is None:
+        amplitude = max_shift - 2.5
+    if not df:
+        D0 = 1.0
+    m = int(np.ceil(abs(amplitude))) + 2                 # rows of speckle beyond the block on either side
+    n = b - a
+    u_row, u_col = displacement_field(n, W, amplitude, rows=np.arange(a, b), H_full=H_full)
+    yy, xx = np.meshgrid(np.arange(n, dtype=np.float64) + m, np.arange(W, dtype=np.float64), indexing="ij")
+    coords = np.stack([yy + u_row, xx + u_col])
+    ref = np.empty((K, n, W), dtype=np.float64)
+    sam = np.empty((K, n, W), dtype=np.float64)
+    for k in range(K):
+        big = _speckle(n + 2 * m, W, 1000 + k + seed)
+        ref[k] = big[m:m + n]
+        warped = map_coordinates(big, coords, order=order, mode="reflect")
+        rng = np.random.default_rng(2000 + k + seed)
+        sam[k] = T0 * (D0 * (warped - 1.0) + 1.0) + noise * rng.standard_normal((n, W))
+    return sam, ref
