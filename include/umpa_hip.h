@@ -71,6 +71,8 @@ const char *umpa_hip_version(void);
  * :963-968; called from model.pyx:769, :835, :911).  Host frames are copied to the device
  * once here and stay resident for the model's lifetime (the reference keeps borrowed host
  * pointers instead, model.pyx:123-129).  mask may be NULL.  pos is [Na][2], >= 0.
+ * padding >= Nw + max_shift, and >= Nw + max_shift + 8 for UMPA_HIP_KIND_DFKERNEL, whose on-the-fly blur
+ * reads 8 pixels further (KERNEL_WINDOW_SIZE, Model.h:7; safe_crop, model.pyx:904); less is UMPA_HIP_E_ARG.
  * Returns NULL on error.
  */
 umpa_hip_model *umpa_hip_create(int kind, int Na, const int *dims,

@@ -34,7 +34,7 @@
 
 #define BLUR_HALF 8                               /* lib/Model.h:7  KERNEL_WINDOW_SIZE */
 #define BLUR_SIDE (2 * BLUR_HALF + 1)
-#define CALL_CAP  500                             /* lib/Optim.cpp:14 MAX_CALLS */
+static int CALL_CAP = 500;                        /* lib/Optim.cpp:14 MAX_CALLS; UMPA_CALL_CAP in the environment lowers it (tests) */
 
 typedef struct {
     int kind, Na, Nw, max_shift, padding;
@@ -394,6 +394,7 @@ void *umpaor_create(int kind, int Na, const int *dims, double *const *sam, doubl
                     double *const *mask, const int *pos, int Nw, const double *win,
                     int max_shift, int padding)
 {
+    if (getenv("UMPA_CALL_CAP")) CALL_CAP = atoi(getenv("UMPA_CALL_CAP")) > 0 ? atoi(getenv("UMPA_CALL_CAP")) : 1; else CALL_CAP = 500;
     oracle_model *m = (oracle_model *)calloc(1, sizeof(*m));
     m->kind = kind; m->Na = Na; m->Nw = Nw; m->max_shift = max_shift; m->padding = padding;
     m->subpx = -1; m->ref_mode = 0; m->has_mask = mask != NULL;   /* lib/Model.cpp:214-215 */

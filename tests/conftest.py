@@ -55,6 +55,11 @@ class Case:
             return np.ascontiguousarray(z[key], dtype=np.float64)
 
         self.sam, self.ref, self.mask = frames("sam"), frames("ref"), frames("mask")
+        gen = self.meta.get("generator")
+        if gen:                                                     # inputs stored as the parameters of a generator
+            from umpa_amd import synth
+            kw = {k: v for k, v in gen.items() if k != "func"}
+            self.sam, self.ref = getattr(synth, gen["func"])(**kw)
         self.z = z
 
     def expected(self, n):
@@ -100,7 +105,7 @@ class Case:
 
 
 ALL_CASES = ["A_small", "B_walks", "C_mask", "C_mask_ones", "D_stepping", "E_dfkernel",
-             "F7_C1_ms2", "F7_C1_ms4", "F8_C2_crop", "F8_C3_crop"]
+             "F7_C1_ms2", "F7_C1_ms4", "F8_C2_crop", "F8_C3_crop", "H_cap"]
 
 
 # ----------------------------------------------------------------------------- the parity bar

@@ -104,9 +104,11 @@ def run_variant(RM, data, v):
     return out
 
 
-def save_case(name, data, variants, RM, f32_inputs=False):
+def save_case(name, data, variants, RM, f32_inputs=False, generator=None):
     arrays = {}
     for key in ("sam", "ref", "mask"):
+        if generator is not None:
+            break                                        # inputs are regenerated from `generator` (umpa_amd.synth)
         if data.get(key) is not None:
             frames = data[key]
             if isinstance(frames, np.ndarray):
@@ -116,7 +118,7 @@ def save_case(name, data, variants, RM, f32_inputs=False):
                     arrays["%s_%d" % (key, k)] = fr
     meta = dict(Nw=data["Nw"], max_shift=data["max_shift"], pos=data.get("pos"),
                 ragged=not isinstance(data["sam"], np.ndarray), f32_inputs=f32_inputs,
-                variants=variants)
+                variants=variants, generator=generator)
     for n, v in enumerate(variants):
         out = run_variant(RM, data, v)
         for k, a in out.items():
@@ -134,10 +136,24 @@ def quantise32(a):
     return a.astype(np.float32).astype(np.float64)
 
 
+def case_H_cap(RM):
+    # ---- case H: the 500-call cap (Optim.cpp:14).  A valley along the shift diagonal keeps the walk zigzagging
+    # (probe, probe, move, switch axis, ...) until MAX_CALLS stops it: the cap is tested at the loop header only
+    # (Optim.cpp:267), so walks end with 500..509 calls depending on where in an iteration they were.
+    from umpa_amd.synth import valley_stack
+    gen = dict(func="valley_stack", n=408, D=150, q=32.0, K=1)
+    sam, ref = valley_stack(gen["n"], gen["D"], gen["q"], gen["K"])
+    save_case("H_cap", dict(sam=sam, ref=ref, Nw=1, max_shift=200),
+              [dict(model="UMPAModelNoDF"), dict(model="UMPAModelDF"), dict(model="UMPAModelNoDF", assign="ref")],
+              RM, generator=gen)
+
+
 def main():
     build_reference("--rebuild" in sys.argv)
     RM = import_reference()
     from umpa_amd.synth import make_stack
+    if "--only-H" in sys.argv:
+        return case_H_cap(RM)
 
     # ---- F1: sub-pixel fit known-answer tests.  NB the reference's wrapper names are swapped:
     # model.spmq -> C++ spmin, model.spm -> C++ spmin_quad (model.pyx:31-80).
@@ -255,6 +271,7 @@ def main():
     sam, ref, _ = make_stack(62, 94, 20, 8, df=True, seed=70, amplitude=5.5)
     save_case("F8_C3_crop", dict(sam=quantise32(sam), ref=quantise32(ref), Nw=7, max_shift=8),
               [dict(model="UMPAModelDF")], RM, f32_inputs=True)
+    case_H_cap(RM)
 
 
 if __name__ == "__main__":

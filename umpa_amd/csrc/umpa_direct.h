@@ -28,6 +28,8 @@ struct ModelDev {
     double win_sum;            // sum of win in row-major order (the `denom` of Model.cpp:724-739)
     int Na, Nw, ms, padding;
     int subpx, ref_mode;
+    int call_cap;              // MAX_CALLS of Optim.cpp:14 (500; UMPA_CALL_CAP in the environment of the creating process
+                               // lowers it for the tests that pin the behaviour at the cap)
 };
 
 struct RegionArgs {
@@ -265,7 +267,7 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
         double c = 0.0;
         Fit fit = w.live;
         const int st = eval_direct<KIND, MASK, NWC>(m, i, j, w.req_i, w.req_j, c, fit, kern, A.kern_stride);
-        walk_feed(w, memo, st, c, fit);
+        walk_feed(w, memo, st, c, fit, m.call_cap);
     }
     double nb[16];
     walk_finish(w, memo, m.subpx, nb);

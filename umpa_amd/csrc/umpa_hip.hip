@@ -61,7 +61,7 @@ struct TimedLaunch { int name; hipEvent_t t0, t1; double fma; };
 } // namespace
 
 struct umpa_hip_model {
-    int kind = 0, Na = 0, Nw = 0, ms = 0, padding = 0, subpx = -1, ref_mode = 0;
+    int kind = 0, Na = 0, Nw = 0, ms = 0, padding = 0, subpx = -1, ref_mode = 0, call_cap = UMPA_CALL_CAP;
     int device = 0;
     bool has_mask = false, owns_frames = true;
     std::vector<int> dims, pos;
@@ -87,7 +87,7 @@ struct umpa_hip_model {
     {
         ModelDev d;
         d.frames = d_desc; d.win = d_win; d.win_sum = win_sum;
-        d.Na = Na; d.Nw = Nw; d.ms = ms; d.padding = padding; d.subpx = subpx; d.ref_mode = ref_mode;
+        d.Na = Na; d.Nw = Nw; d.ms = ms; d.padding = padding; d.subpx = subpx; d.ref_mode = ref_mode; d.call_cap = call_cap;
         return d;
     }
 };
@@ -235,6 +235,9 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
     // stepped regions: the tiled kernels still compute the dense grid, which pays while step0*step1 is small
     // (the direct kernel's cost is per requested pixel, about 20x the tiled cost per dense pixel)
     if (A.step0 * A.step1 > 9) return false;
+    // the exhaustive table has (2 max_shift - 1)^2 planes: beyond a few hundred shifts the lazy evaluation of the
+    // direct kernel (about 20 costs per pixel) is less work than filling it
+    if ((2 * m->ms - 1) * (2 * m->ms - 1) > 1089) return false;
     // the region must keep every window inside the frames even for the partial tiles' halo reads: guaranteed
     // by check_region + clamped staging.  Separable window required (always true for the Hamming window).
     if (!m->tiled.separable || m->tiled.sep_nw != m->Nw) return false;
@@ -282,8 +285,11 @@ umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const
         fail(UMPA_HIP_E_ARG, "unknown model kind %d", kind);
         return nullptr;
     }
-    if (Na <= 0 || !dims || !sam || !ref || !pos || !win || Nw < 0 || max_shift < 0 || padding < Nw + max_shift) {
-        fail(UMPA_HIP_E_ARG, "bad arguments to umpa_hip_create (Na=%d Nw=%d max_shift=%d padding=%d)", Na, Nw, max_shift, padding);
+    // the kernel-dark-field model blurs the reference on the fly: its reads reach UMPA_BLUR_HALF pixels further (safe_crop, model.pyx:904)
+    const int reach = kind == UMPA_HIP_KIND_DFKERNEL ? UMPA_BLUR_HALF : 0;
+    if (Na <= 0 || !dims || !sam || !ref || !pos || !win || Nw < 0 || max_shift < 0 || padding < Nw + max_shift + reach) {
+        fail(UMPA_HIP_E_ARG, "bad arguments to umpa_hip_create (Na=%d Nw=%d max_shift=%d padding=%d, needs padding >= Nw + max_shift + %d)",
+             Na, Nw, max_shift, padding, reach);
         return nullptr;
     }
     int ndev = 0;
@@ -297,6 +303,7 @@ umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const
     umpa_hip_model* m = new (std::nothrow) umpa_hip_model;
     if (!m) { fail(UMPA_HIP_E_NOMEM, "out of host memory"); return nullptr; }
     m->kind = kind; m->Na = Na; m->ms = max_shift; m->padding = padding; m->device = device;
+    if (const char* cap = getenv("UMPA_CALL_CAP")) m->call_cap = std::max(1, atoi(cap));
     m->has_mask = mask != nullptr;
     m->owns_frames = !(flags & UMPA_HIP_F_DEVICE_FRAMES);
     m->dims.assign(dims, dims + 2 * Na);
@@ -389,8 +396,9 @@ int umpa_hip_set_window(umpa_hip_model* m, const double* win, int Nw)
     if (Nw < 0) return fail(UMPA_HIP_E_ARG, "Nw must be non-negative.");           // Model.cpp:242
     // The reference does not re-derive the padding when the window grows (model.pyx:702-704) and
     // then reads outside the frames.  Refuse that instead of faulting the GPU.
-    if (Nw + m->ms > m->padding)
-        return fail(UMPA_HIP_E_ARG, "Nw=%d with max_shift=%d exceeds the padding %d fixed at construction", Nw, m->ms, m->padding);
+    const int reach = m->kind == UMPA_HIP_KIND_DFKERNEL ? UMPA_BLUR_HALF : 0;
+    if (Nw + m->ms + reach > m->padding)
+        return fail(UMPA_HIP_E_ARG, "Nw=%d with max_shift=%d (+%d) exceeds the padding %d fixed at construction", Nw, m->ms, reach, m->padding);
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
     return upload_win(m, win, Nw);

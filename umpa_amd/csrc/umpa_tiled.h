@@ -314,7 +314,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
         double c = 0.0;
         Fit fit = w.live;
         const int st = eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, c, fit);
-        walk_feed(w, memo, st, c, fit);
+        walk_feed(w, memo, st, c, fit, m.call_cap);
     }
     double nb[16];
     walk_finish(w, memo, (R.ablate & 2) ? 0 : m.subpx, nb);

@@ -16,7 +16,7 @@
 #define UMPA_ST_DIM       4
 #define UMPA_ST_POSITIVE  8
 
-#define UMPA_CALL_CAP 500          // Optim.cpp:14
+#define UMPA_CALL_CAP 500          // Optim.cpp:14 (the default of ModelDev::call_cap)
 #define UMPA_TIE      1e-8         // Optim.cpp:243
 
 namespace umpa {
@@ -211,7 +211,7 @@ __device__ inline void memo_shift(Memo d, int axis, int dir)
 // snapshot `args_copy = *args` (:296,327) depends on which one it was.  The centre value rides in a
 // register (`c0`): after a move it is the neighbour that was just compared.
 template <class Memo>
-__device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit)
+__device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit, int call_cap = UMPA_CALL_CAP)
 {
     w.n++;                                                      // Ncalls counts failed calls too (Optim.cpp:263-264)
     if (!(st & UMPA_ST_OK)) {                                   // any failed call returns at once, outputs as they stand
@@ -220,7 +220,10 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
         return;
     }
     w.live = fit;
-    bool cap_test = true;                                       // the `while (Ncalls < MAX_CALLS)` header, Optim.cpp:267
+    // The call cap is tested in one place only, the `while (Ncalls < MAX_CALLS)` header (Optim.cpp:267): after the
+    // centre evaluation and after every move.  A probe of the low or the high neighbour that reaches the cap still
+    // finishes its iteration (the other probe, then the move or the gather); `goto start` skips the test as well.
+    bool cap_test = w.phase == PH_CENTRE;
     bool scan = false;
     if (w.phase == PH_GATHER) {                                 // Optim.cpp:353-378
         const int r = w.g >> 2, c = w.g & 3;
@@ -233,7 +236,6 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
             w.c0 = val;
             w.live = w.kept;                                    // stale on purpose (Optim.cpp:373)
             w.found0 = w.found1 = 0;
-            cap_test = false;                                   // `goto start` skips the call-cap test
         } else {
             w.need &= w.need - 1;
             scan = true;
@@ -257,7 +259,7 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
     }
 
     while (!scan) {
-        if (cap_test && w.n >= UMPA_CALL_CAP) {
+        if (cap_test && w.n >= call_cap) {
             w.status = st & ~UMPA_ST_OK;                        // Optim.cpp:477
             w.phase = PH_DONE;
             return;

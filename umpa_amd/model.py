@@ -34,6 +34,13 @@ NPDOUBLE = np.dtype("float64")
 KIND_NODF, KIND_DF, KIND_DFKERNEL = 0, 1, 2
 
 
+def _cround(x):
+    """libc round(): halves away from zero (the reference's `from libc.math cimport round`, model.pyx:20);
+    Python's round() goes to the even neighbour."""
+    x = float(x)
+    return int(np.sign(x) * np.floor(abs(x) + 0.5))
+
+
 def _default_device():
     if "UMPA_HIP_DEVICE" in os.environ:
         return int(os.environ["UMPA_HIP_DEVICE"])
@@ -522,7 +529,7 @@ class UMPAModelNoDF(UMPAModelBase):
     def cost(self, i, j, sx, sy):
         """Cost and transmission at pixel (i, j) for the shift (sx rows, sy columns), rounded."""
         values = np.zeros(2)
-        self._lib.check(self._lib.cost(self._handle, int(i), int(j), int(round(sx)), int(round(sy)),
+        self._lib.check(self._lib.cost(self._handle, int(i), int(j), _cround(sx), _cround(sy),
                                        _lib._ptr(values, _lib._dp)), "cost")
         return (values[0], values[1])
 
@@ -544,7 +551,7 @@ class UMPAModelDF(UMPAModelBase):
 
     def cost(self, i, j, sx, sy):
         values = np.zeros(3)
-        self._lib.check(self._lib.cost(self._handle, int(i), int(j), int(round(sx)), int(round(sy)),
+        self._lib.check(self._lib.cost(self._handle, int(i), int(j), _cround(sx), _cround(sy),
                                        _lib._ptr(values, _lib._dp)), "cost")
         return (values[0], values[1], values[2])
 
@@ -575,7 +582,7 @@ class UMPAModelDFKernel(UMPAModelBase):
     def cost(self, i, j, sx, sy, a, b, c):
         values = np.zeros(5)
         values[2], values[3], values[4] = a, b, c
-        self._lib.check(self._lib.cost(self._handle, int(i), int(j), int(round(sx)), int(round(sy)),
+        self._lib.check(self._lib.cost(self._handle, int(i), int(j), _cround(sx), _cround(sy),
                                        _lib._ptr(values, _lib._dp)), "cost")
         return (values[0], values[1])
 

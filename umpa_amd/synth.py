@@ -116,3 +116,18 @@ def make_block(rows, H_full, W, K, max_shift, df=True, seed=0, T0=0.8, D0=0.7, n
         rng = np.random.default_rng(2000 + k + seed)
         sam[k] = T0 * (D0 * (warped - 1.0) + 1.0) + noise * rng.standard_normal((n, W))
     return sam, ref
+
+
+def valley_stack(n, D, q, K=1):
+    """A stack whose cost landscape is a long narrow valley along the shift diagonal: the walk zigzags down it for
+    hundreds of evaluations (tests of the 500-call cap, Optim.cpp:14,267).  Every value is an exactly reproducible
+    IEEE expression of small integers, so the fixture stores the parameters instead of the arrays."""
+    m = n + D
+    y = np.arange(m, dtype=np.float64)[:, None]
+    x = np.arange(m, dtype=np.float64)[None, :]
+    sam, ref = [], []
+    for k in range(K):
+        big = 1.0 + 0.5 * ((x - y + k) / q) ** 2 + ((x + y) / 4096.0) ** 2
+        ref.append(np.ascontiguousarray(big[:n, :n]))
+        sam.append(np.ascontiguousarray(0.75 * big[D:D + n, D:D + n]))
+    return np.stack(sam), np.stack(ref)
