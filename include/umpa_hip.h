@@ -140,6 +140,14 @@ int umpa_hip_spmin_quad(int device, const double *a16, double *pos2, double *val
 int umpa_hip_correct_bad_pixels(const double *in, double *out, long nimg, int H, int W, int ndims,
                                 double lo, double hi, int iterations, int device, int flags, void *stream);
 
+/* Page-locked host memory for the arrays of the host-array entry points (result maps above all: 181 MB per C2
+ * match): into such memory the download is a DMA at PCIe rate that overlaps the matching of the next row chunk;
+ * into pageable memory the runtime has to stage it.  Blocks handed back are kept pinned in a pool (pinning is the
+ * slow part) until umpa_hip_host_trim().  The reference's arrays are ordinary numpy allocations (model.pyx:442-474). */
+void *umpa_hip_host_alloc(size_t bytes);
+void  umpa_hip_host_free(void *p);
+void  umpa_hip_host_trim(void);
+
 /* instrumentation used by bench.py for the roofline line: when enabled every kernel launch is
  * bracketed by HIP events on its launch stream; collect() waits for them and folds them into
  * per-kernel totals (returns the number of distinct kernels), read() returns one total. */

@@ -26,7 +26,7 @@ _dpp = C.POINTER(_dp)
 HIP_SYMBOLS = [
     "device_count", "last_error", "version", "create", "destroy", "set_window", "set_subpx",
     "set_reference_shift", "coverage", "coverage_region", "cost", "min", "match_region",
-    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path",
+    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path", "host_alloc", "host_free", "host_trim",
     "update_frames", "correct_bad_pixels",
 ]
 
@@ -76,6 +76,9 @@ class Native:
             f("timing_collect", C.c_int, [C.c_void_p])
             f("timing_read", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), _dp, _ip])
             f("timing_fma", C.c_int, [C.c_void_p, C.c_int, _dp])
+            f("host_alloc", C.c_void_p, [C.c_size_t])
+            f("host_free", None, [C.c_void_p])
+            f("host_trim", None, [])
             f("last_path", C.c_int, [C.c_void_p])
             f("update_frames", C.c_int, [C.c_void_p, _dpp, _dpp])
             f("correct_bad_pixels", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
@@ -128,6 +131,26 @@ def hip():
         _pin_hip_runtime()
         _hip = Native(HIP_LIB_PATH, "umpa_hip_", True)
     return _hip
+
+
+def pinned_empty(shape, dtype, zero=False):
+    """A numpy array in page-locked host memory from the library's pool (``umpa_hip_host_alloc``): the result maps of
+    the host-array API are downloaded into such arrays at PCIe rate.  The block goes back to the pool when the last
+    view of the array is gone.  Falls back to an ordinary array if pinning fails (the download is then staged)."""
+    import weakref
+    import numpy as np
+    lib = hip()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    ptr = lib.host_alloc(max(n, 1))
+    if not ptr:
+        return (np.zeros if zero else np.empty)(shape, dtype=dt)
+    buf = (C.c_char * max(n, 1)).from_address(ptr)
+    weakref.finalize(buf, lib.host_free, ptr)
+    a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    if zero:
+        a[...] = 0
+    return a
 
 
 class FrameSet:

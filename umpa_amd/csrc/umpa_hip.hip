@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cmath>
 #include <algorithm>
+#include <mutex>
+#include <functional>
 
 #include "../../include/umpa_hip.h"
 #include "umpa_walk.h"
@@ -72,6 +74,7 @@ struct umpa_hip_model {
     std::vector<double> win;
     double win_sum = 0.0;
     hipStream_t stream = nullptr;                  // used by the host-I/O entry points
+    hipStream_t copy_stream = nullptr;             // downloads of finished row chunks, behind the compute stream
     DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small, b_kern;
     TiledState tiled;                              // scratch of the tiled fast path
     int last_path = 0;
@@ -244,7 +247,8 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
     return tiled_supported(m->Nw, m->ms, m->Na);
 }
 
-int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s)
+int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
+              int pieces = 1, const std::function<void(int, int)>& on_rows = nullptr)
 {
     const bool can_tile = tiled_applicable(m, A);
     if ((flags & UMPA_HIP_F_FORCE_TILED) && !can_tile)
@@ -253,14 +257,16 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s)
         TiledTimers tt;
         tt.get = [m]() { return get_event(m); };
         int rc = tiled_match(m->tiled, m->dev(), m->kind, m->dims[0], m->dims[1], A, s,
-                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0);
+                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, pieces, on_rows);
         if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
         if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
         for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; m->launches.push_back(tl); }
         m->last_path = 2;
         return 0;
     }
-    return run_direct(m, A, s);
+    const int rc = run_direct(m, A, s);
+    if (rc == 0 && on_rows) on_rows(0, A.N0);
+    return rc;
 }
 
 } // namespace
@@ -315,7 +321,8 @@ umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const
             return nullptr;
         }
     }
-    bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) == hipSuccess;
 
     m->d_sam.resize(Na); m->d_ref.resize(Na); m->d_mask.assign(Na, nullptr);
     if (ok && m->owns_frames) {
@@ -378,6 +385,7 @@ void umpa_hip_destroy(umpa_hip_model* m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
     for (auto& l : m->launches) { (void)hipEventDestroy(l.t0); (void)hipEventDestroy(l.t1); }
     for (auto e : m->event_pool) (void)hipEventDestroy(e);
     tiled_release(m->tiled);
@@ -387,6 +395,7 @@ void umpa_hip_destroy(umpa_hip_model* m)
     if (m->d_win) (void)hipFree(m->d_win);
     if (m->d_frames_blob) (void)hipFree(m->d_frames_blob);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     delete m;
 }
 
@@ -527,22 +536,56 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
         HIP_TRY(hipMemcpyAsync(m->b_cover.p, covermap, n * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
         A.cover = (const double*)m->b_cover.p;
     }
+    // The debug maps are written for every pixel the kernels visit: they only need clearing where the coverage test
+    // may skip pixels (1.4 GB of memset per C2 match otherwise).
+    const bool clear_dbg = covermap != nullptr;
     if (dbg_d) { if (m->b_dd.reserve(n * 25 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_d buffer");
-                 HIP_TRY(hipMemsetAsync(m->b_dd.p, 0, n * 25 * sizeof(double), s), UMPA_HIP_E_DEVICE); A.dbg_d = (double*)m->b_dd.p; }
+                 if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_dd.p, 0, n * 25 * sizeof(double), s), UMPA_HIP_E_DEVICE);
+                 A.dbg_d = (double*)m->b_dd.p; }
     if (dbg_a) { if (m->b_da.reserve(n * 16 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_a buffer");
-                 HIP_TRY(hipMemsetAsync(m->b_da.p, 0, n * 16 * sizeof(double), s), UMPA_HIP_E_DEVICE); A.dbg_a = (double*)m->b_da.p; }
+                 if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_da.p, 0, n * 16 * sizeof(double), s), UMPA_HIP_E_DEVICE);
+                 A.dbg_a = (double*)m->b_da.p; }
     if (dbg_ncalls) { if (m->b_dn.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "debug_Ncalls buffer");
-                      HIP_TRY(hipMemsetAsync(m->b_dn.p, 0, n * sizeof(int), s), UMPA_HIP_E_DEVICE); A.dbg_n = (int*)m->b_dn.p; }
+                      if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_dn.p, 0, n * sizeof(int), s), UMPA_HIP_E_DEVICE);
+                      A.dbg_n = (int*)m->b_dn.p; }
 
-    if (int rc = run_match(m, A, flags, s)) return rc;
+    // The region is matched in a few row chunks; all kernels are enqueued first (each chunk leaves an event on the
+    // compute stream), then the rows of chunk c travel to the host on the copy stream while chunk c+1 is still
+    // being matched.  Into pinned host memory (umpa_hip_host_alloc) that is a DMA at PCIe rate; into pageable memory
+    // the runtime stages it, still overlapped with the compute.
+    struct Piece { int lo, hi; hipEvent_t done; };
+    std::vector<Piece> piece_list;
+    auto on_rows = [&](int lo, int hi) {
+        Piece p = {lo, hi, get_event(m)};
+        if (p.done) (void)hipEventRecord(p.done, s);
+        piece_list.push_back(p);
+    };
+    const int pieces = n >= ((size_t)1 << 20) ? 4 : 1;
+    if (int rc = run_match(m, A, flags, s, pieces, on_rows)) return rc;
 
-    HIP_TRY(hipMemcpyAsync(values, A.values, n * nparam * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
-    HIP_TRY(hipMemcpyAsync(err, A.err, n * sizeof(int), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
-    if (uv) HIP_TRY(hipMemcpyAsync(uv, A.uv, n * 2 * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
-    if (dbg_d) HIP_TRY(hipMemcpyAsync(dbg_d, A.dbg_d, n * 25 * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
-    if (dbg_a) HIP_TRY(hipMemcpyAsync(dbg_a, A.dbg_a, n * 16 * sizeof(double), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
-    if (dbg_ncalls) HIP_TRY(hipMemcpyAsync(dbg_ncalls, A.dbg_n, n * sizeof(int), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
-    HIP_TRY(hipStreamSynchronize(s), UMPA_HIP_E_DEVICE);
+    hipStream_t cs = m->copy_stream;
+    hipError_t ce = hipSuccess;
+    auto down = [&](void* host, const void* dev, size_t elem_bytes, size_t per_px, int lo, int hi) {
+        if (ce != hipSuccess || !host) return;
+        const size_t off = (size_t)lo * N1 * per_px * elem_bytes, bytes = (size_t)(hi - lo) * N1 * per_px * elem_bytes;
+        ce = hipMemcpyAsync((char*)host + off, (const char*)dev + off, bytes, hipMemcpyDeviceToHost, cs);
+    };
+    for (const Piece& p : piece_list) {
+        if (p.done) { if (ce == hipSuccess) ce = hipStreamWaitEvent(cs, p.done, 0); }
+        else if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+        if (planar) for (int k = 0; k < nparam; k++) down(values + (size_t)k * n, A.values + (size_t)k * n, sizeof(double), 1, p.lo, p.hi);
+        else down(values, A.values, sizeof(double), nparam, p.lo, p.hi);
+        down(err, A.err, sizeof(int), 1, p.lo, p.hi);
+        down(uv, A.uv, sizeof(double), 2, p.lo, p.hi);
+        down(dbg_d, A.dbg_d, sizeof(double), 25, p.lo, p.hi);
+        down(dbg_a, A.dbg_a, sizeof(double), 16, p.lo, p.hi);
+        down(dbg_ncalls, A.dbg_n, sizeof(int), 1, p.lo, p.hi);
+    }
+    if (ce == hipSuccess) ce = hipStreamSynchronize(cs);
+    const hipError_t se = hipStreamSynchronize(s);
+    for (const Piece& p : piece_list) if (p.done) m->event_pool.push_back(p.done);
+    if (ce != hipSuccess) return fail(UMPA_HIP_E_DEVICE, "download of the result maps: %s", hipGetErrorString(ce));
+    if (se != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "match kernels: %s", hipGetErrorString(se));
     return UMPA_HIP_ST_OK;
 }
 
@@ -645,6 +688,63 @@ int umpa_hip_correct_bad_pixels(const double* in, double* out, long nimg, int H,
     (void)hipFree(blob);
     if (e != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "correct_bad_pixels: %s", hipGetErrorString(e));
     return 0;
+}
+
+/* ---- pinned host memory for result maps (and inputs): a small pool, because pinning is slow (page-locking) and a
+ * caller that matches in a loop asks for the same sizes again and again */
+namespace {
+struct HostBlock { void* p; size_t cap; };
+std::mutex g_host_mu;
+std::vector<HostBlock> g_host_free;                 // blocks handed back, kept pinned
+std::vector<HostBlock> g_host_live;
+size_t g_host_cached = 0;
+const size_t HOST_CACHE_LIMIT = (size_t)8 << 30;
+}
+
+void* umpa_hip_host_alloc(size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    size_t best = g_host_free.size();
+    for (size_t q = 0; q < g_host_free.size(); q++)
+        if (g_host_free[q].cap >= bytes && g_host_free[q].cap <= bytes + bytes / 4 + 4096 &&
+            (best == g_host_free.size() || g_host_free[q].cap < g_host_free[best].cap)) best = q;
+    HostBlock b;
+    if (best < g_host_free.size()) {
+        b = g_host_free[best];
+        g_host_free.erase(g_host_free.begin() + best);
+        g_host_cached -= b.cap;
+    } else {
+        b.cap = (bytes + 4095) & ~(size_t)4095;
+        if (hipHostMalloc(&b.p, b.cap, hipHostMallocDefault) != hipSuccess) {
+            fail(UMPA_HIP_E_NOMEM, "cannot pin %zu bytes of host memory", b.cap);
+            return nullptr;
+        }
+    }
+    g_host_live.push_back(b);
+    return b.p;
+}
+
+void umpa_hip_host_free(void* p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    for (size_t q = 0; q < g_host_live.size(); q++)
+        if (g_host_live[q].p == p) {
+            HostBlock b = g_host_live[q];
+            g_host_live.erase(g_host_live.begin() + q);
+            if (g_host_cached + b.cap <= HOST_CACHE_LIMIT) { g_host_free.push_back(b); g_host_cached += b.cap; }
+            else (void)hipHostFree(b.p);
+            return;
+        }
+}
+
+void umpa_hip_host_trim(void)
+{
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    for (auto& b : g_host_free) (void)hipHostFree(b.p);
+    g_host_free.clear();
+    g_host_cached = 0;
 }
 
 int umpa_hip_timing_enable(umpa_hip_model* m, int on)

@@ -520,8 +520,12 @@ inline size_t tiled_table_budget()
 
 // One match of a region on the tiled path.  Returns 0, -3 (allocation) or a positive hipError_t.
 // `reuse_ref_maps`: the caller vouches that the reference frames are those of the previous call (it owns them).
+// `pieces` > 1: split the region into about that many row chunks even where the table budget would allow one (the
+// host-array entry point downloads the rows of chunk c while chunk c+1 is being matched); `on_rows(xi_lo, xi_hi)`
+// is called after the kernels of a chunk have been enqueued.
 inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const RegionArgs& A,
-                       hipStream_t s, TiledTimers* tt, bool reuse_ref_maps)
+                       hipStream_t s, TiledTimers* tt, bool reuse_ref_maps,
+                       int pieces = 1, const std::function<void(int, int)>& on_rows = nullptr)
 {
     const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1;
     const size_t plane = (size_t)H * W;
@@ -550,6 +554,10 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
     if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
     if (rows_chunk > N0d) rows_chunk = ((long)N0d + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+    if (pieces > 1) {
+        const long want = (((long)N0d + pieces - 1) / pieces + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+        if (want < rows_chunk) rows_chunk = std::max<long>(want, 4 * UMPA_TILE);
+    }
     {   // eval_lookup multiplies the slot number by a 32-bit slot stride (rows_chunk * N1d)
         const long cap = (long)(0xffffffffull / (size_t)N1d) / UMPA_TILE * UMPA_TILE;
         if (cap < UMPA_TILE) return (int)hipErrorInvalidValue;
@@ -633,6 +641,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         toc();
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
+        if (on_rows) on_rows(xi_lo, xi_hi);
     }
     return 0;
 }

@@ -355,7 +355,7 @@ class UMPAModelBase:
             # one plane per map: the device writes the result maps directly (no host-side de-interleaving)
             planar = True
             shp = (self.Nparam, N0, N1)
-            values = np.empty(shp, dtype=NPDOUBLE) if covermap is None else np.zeros(shp, dtype=NPDOUBLE)
+            values = _lib.pinned_empty(shp, NPDOUBLE, zero=covermap is not None)
         else:
             values = np.zeros(shp, dtype=NPDOUBLE)
 
@@ -364,14 +364,19 @@ class UMPAModelBase:
             uv = np.zeros((N0, N1, 2), dtype=NPDOUBLE)
             uv[:, :, 0] = dxdy[0]
             uv[:, :, 1] = dxdy[1]
-        err = np.empty(sh, dtype=np.int32) if (covermap is None and self._lib.is_hip) else np.zeros(sh, dtype=np.int32)
+        if self._lib.is_hip:                                        # page-locked: downloaded at PCIe rate, chunk by chunk
+            err = _lib.pinned_empty(sh, np.int32, zero=covermap is not None)
+        else:
+            err = np.zeros(sh, dtype=np.int32)
         result = {}
         dd = da = dn = None
         if self.debug:                                              # debug = "ncalls": only the evaluation counts
+            mk = (lambda shape, dt: _lib.pinned_empty(shape, dt, zero=covermap is not None)) if self._lib.is_hip else \
+                 (lambda shape, dt: np.zeros(shape, dtype=dt))
             if self.debug != "ncalls":
-                dd = np.zeros(sh + (25,), dtype=NPDOUBLE)
-                da = np.zeros(sh + (16,), dtype=NPDOUBLE)
-            dn = np.zeros(sh, dtype=np.int32)
+                dd = mk(sh + (25,), NPDOUBLE)
+                da = mk(sh + (16,), NPDOUBLE)
+            dn = mk(sh, np.int32)
 
         vp = lambda a: a.ctypes.data if a is not None else None
         args = [self._handle, s0[0], s0[2], N0, s1[0], s1[2], N1, vp(values), self.Nparam, vp(uv), vp(err),
