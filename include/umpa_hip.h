@@ -59,6 +59,10 @@ extern "C" {
                                         (umpa_hip_update_frames / set_window invalidate); for borrowed device frames the caller vouches.
                                         Results are identical with and without. */
 
+#define UMPA_HIP_F_USE_STAGED      32 /* the stack uploaded by umpa_hip_stage_sample becomes the sample stack of this match */
+#define UMPA_HIP_F_ASYNC           64 /* host-array call: enqueue the kernels and the downloads (into page-locked arrays) and
+                                         return; the arrays are valid after umpa_hip_wait() */
+
 typedef struct umpa_hip_model umpa_hip_model;
 
 /* library-wide */
@@ -85,6 +89,21 @@ umpa_hip_model *umpa_hip_create(int kind, int Na, const int *dims,
  * such as umpa_multi.py:149 builds a new model per projection.  Here the reference stack can stay in HBM
  * while projections stream through. */
 int umpa_hip_update_frames(umpa_hip_model *m, double *const *sam, double *const *ref);
+
+/* The step-scan pipeline of UMPA/umpa_multi.py:133-150 on one GPU: upload the NEXT projection while the current
+ * one is being matched.  raw[k] are host frames of the model's shapes (raw_dtype 0 float64, 1 float32, 2 uint16
+ * detector counts; page-locked memory -- umpa_hip_host_alloc / umpa_hip_host_register -- makes the call return at
+ * once), copied on the model's upload stream and written to the model's BACK sample buffer as
+ * (raw - dark) / flat   (dark[k], flat[k]: device float64 frames, or NULL tables: plain conversion) -- the flat-field
+ * correction of umpa_multi.py:144 fused into the upload.  The staged stack becomes the sample stack at the next
+ * umpa_hip_match_region with UMPA_HIP_F_USE_STAGED, in stream order.  Only for models that own their frames. */
+int umpa_hip_stage_sample(umpa_hip_model *m, const void *const *raw, int raw_dtype,
+                          const double *const *dark, const double *const *flat);
+/* wait for an UMPA_HIP_F_ASYNC match of this model (kernels and downloads); returns its status */
+int umpa_hip_wait(umpa_hip_model *m);
+/* page-lock / release memory the caller owns (a shared-memory ring that feeds umpa_hip_stage_sample) */
+int umpa_hip_host_register(void *p, size_t bytes);
+int umpa_hip_host_unregister(void *p);
 
 /* ~ModelBase (Model.cpp:224) */
 void umpa_hip_destroy(umpa_hip_model *m);

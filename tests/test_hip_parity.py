@@ -227,6 +227,53 @@ def test_update_frames_and_projection_farm(hip_ns):
             np.testing.assert_array_equal(res[p][k], want[p][k])
 
 
+def test_C5_shape_step_scan_against_the_oracle(hip_ns, port_ns):
+    """BASELINE config C5's parameters (5 frames, Nw=5, max_shift=5, dark-field on) on 512 x 512 projections: the streaming
+    pipeline (uint16 counts uploaded into the back buffer + fused flat correction while the previous projection is matched,
+    nearest-reference switching, results in page-locked memory) and the worker-process farm, both against the CPU oracle
+    on what the reference script computes: (proj - dark) / flat[refnum] matched against ref[refnum] (umpa_multi.py:133-150)."""
+    from umpa_amd.farm import ProjectionFarm, StreamingMatcher, nearest_reference
+    from umpa_amd.synth import make_stack
+    Nw, ms, K, n = 5, 5, 5, 512
+    base = [make_stack(n, n, K, ms, df=True, seed=40 + 10 * r, order=1) for r in range(2)]
+    refs = np.stack([b[1] for b in base])
+    rng = np.random.default_rng(9)
+    dark = 100.0 + rng.uniform(0, 2, size=(K, n, n))
+    flats = 20000.0 * (1.0 + 0.05 * rng.standard_normal((2, K, n, n)))
+    ref_nums = [0, 5]
+    raws, want = {}, {}
+    for p in range(6):
+        r = nearest_reference(p, ref_nums)
+        raws[p] = np.rint(np.roll(base[r][0], p, axis=2) * flats[r] + dark).astype(np.uint16)
+        sam = (raws[p].astype(np.float64) - dark) / flats[r]
+        m = port_ns.UMPAModelDF(sam, refs[r], window_size=Nw, max_shift=ms)
+        m.debug = True
+        want[p] = m.match(ROI=((100, 140, 1), (0, n - 2 * (Nw + ms), 1)), quiet=True)       # a 40-row band per projection
+    sm = StreamingMatcher(refs, Nw, ms, df=True, device=0, flats=flats, dark=dark, ref_nums=ref_nums, debug=True)
+    bufs = {}
+    for p in raws:
+        bufs[p] = sm.input_buffer(np.uint16)
+        bufs[p][...] = raws[p]
+    seen = []
+    for pid, res in sm.run((p, bufs[p]) for p in range(6)):
+        seen.append(pid)
+        got = {k: (v[100:140] if isinstance(v, np.ndarray) else v) for k, v in res.items()}
+        assert_parity(got, want[pid], ms, "C5 stream p%d" % pid)
+    assert seen == list(range(6))
+    with ProjectionFarm(refs, Nw, ms, devices=[0], flats=flats, dark=dark, ref_nums=ref_nums, raw_dtype=np.uint16) as farm:
+        res = dict(farm.map(raws.items()))
+    assert sorted(res) == list(range(6))
+    for p in range(6):
+        # the farm returns the maps only (no debug arrays): bit-exact walk outcome, maps to the bar on all but the
+        # unconverged-Newton pixels the streaming leg has just classified
+        np.testing.assert_array_equal(res[p]["err"][100:140], want[p]["err"])
+        ok = want[p]["err"] == 1
+        for k in ("T", "df"):
+            np.testing.assert_allclose(res[p][k][100:140][ok], want[p][k][ok], rtol=1e-5)
+        close = np.abs(res[p]["dx"][100:140] - want[p]["dx"]) <= 1e-5 * np.maximum(1.0, np.abs(want[p]["dx"]))
+        assert (~close & ok).sum() <= 4
+
+
 def test_plain_c_host_of_the_c_abi(hip_ns, tmp_path):
     """examples/c_host.c: the boundary is a C ABI -- a host with no Python and no PyTorch in the process."""
     import subprocess

@@ -136,6 +136,24 @@ def test_projection_farm_on_cpu_workers():
         for k in ("f", "T", "dx", "dy", "df", "err"):
             np.testing.assert_array_equal(got[p][k], want[k])
 
+    # the flat-field form of umpa_multi.py:133-145: uint16 counts, dark frame, one flat and one reference stack per
+    # reference acquisition, nearest reference per projection number
+    rng = np.random.default_rng(3)
+    refs = np.stack([stacks[0][1], stacks[1][1]])
+    dark = 90.0 + rng.uniform(0, 2, size=ref.shape)
+    flats = 9000.0 * (1.0 + 0.05 * rng.standard_normal((2,) + ref.shape))
+    ref_nums = [0, 9]
+    raws = {p: np.rint(stacks[p % 3][0] * flats[0 if p < 5 else 1] + dark).astype(np.uint16) for p in (1, 4, 5, 8)}
+    with ProjectionFarm(refs, Nw, ms, devices=[None], flats=flats, dark=dark, ref_nums=ref_nums, raw_dtype=np.uint16,
+                        model=("oracle.cpu_model", "port.UMPAModelDF")) as farm:
+        got = dict(farm.map(raws.items(), num_threads=1))
+    for p, raw in raws.items():
+        r = 0 if p < 5 else 1
+        sam = (raw.astype(np.float64) - dark) / flats[r]
+        want = cpu_model.port.UMPAModelDF(sam, refs[r], window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
+        for k in ("f", "T", "dx", "dy", "df", "err"):
+            np.testing.assert_array_equal(got[p][k], want[k])
+
 
 def _gpu_worker(rank, world, port, tmp):
     """Two ranks, one process each, both on the one GPU of the test box (the 8-GPU run is the driver's): slabs are

@@ -16,7 +16,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "libumpa_hip.so")
 
 ST_OK, ST_BOUND, ST_DIM, ST_POSITIVE = 1, 2, 4, 8
 F_DEVICE_FRAMES = 1
-F_DEVICE_IO, F_FORCE_DIRECT, F_FORCE_TILED, F_PLANAR, F_REUSE_REF_MAPS = 1, 2, 4, 8, 16
+F_DEVICE_IO, F_FORCE_DIRECT, F_FORCE_TILED, F_PLANAR, F_REUSE_REF_MAPS, F_USE_STAGED, F_ASYNC = 1, 2, 4, 8, 16, 32, 64
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -26,7 +26,7 @@ _dpp = C.POINTER(_dp)
 HIP_SYMBOLS = [
     "device_count", "last_error", "version", "create", "destroy", "set_window", "set_subpx",
     "set_reference_shift", "coverage", "coverage_region", "cost", "min", "match_region",
-    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path", "host_alloc", "host_free", "host_trim",
+    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path", "host_alloc", "host_free", "host_trim", "stage_sample", "wait", "host_register", "host_unregister",
     "update_frames", "correct_bad_pixels",
 ]
 
@@ -79,6 +79,10 @@ class Native:
             f("host_alloc", C.c_void_p, [C.c_size_t])
             f("host_free", None, [C.c_void_p])
             f("host_trim", None, [])
+            f("stage_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
+            f("wait", C.c_int, [C.c_void_p])
+            f("host_register", C.c_int, [C.c_void_p, C.c_size_t])
+            f("host_unregister", C.c_int, [C.c_void_p])
             f("last_path", C.c_int, [C.c_void_p])
             f("update_frames", C.c_int, [C.c_void_p, _dpp, _dpp])
             f("correct_bad_pixels", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,

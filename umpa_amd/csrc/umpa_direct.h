@@ -304,6 +304,22 @@ __global__ void coverage_kernel(ModelDev m, int org0, int step0, int N0, int org
     gpw(out)[(size_t)xi * N1 + xj] = c;
 }
 
+// Flat-field correction fused into the upload of a projection (UMPA/umpa_multi.py:144: sam = (proj - dark) / flat[refnum]):
+// `raw` is the detector frame as it came over PCIe (float64, float32 or uint16 counts), `out` the model's float64
+// sample frame.  dark / flat may be NULL (plain conversion).
+template <class T>
+__global__ void __launch_bounds__(256)
+flat_correct_kernel(const T* __restrict__ raw, const double* __restrict__ dark, const double* __restrict__ flat,
+                    double* __restrict__ out, size_t n)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    double v = (double)gp(raw)[q];
+    if (dark) v -= gp(dark)[q];
+    if (flat) v /= gp(flat)[q];
+    gpw(out)[q] = v;
+}
+
 __global__ void spfit_kernel(const double* a, double* io, int quad)
 {
     double x = io[0], y = io[1];

@@ -75,6 +75,18 @@ struct umpa_hip_model {
     double win_sum = 0.0;
     hipStream_t stream = nullptr;                  // used by the host-I/O entry points
     hipStream_t copy_stream = nullptr;             // downloads of finished row chunks, behind the compute stream
+    // double-buffered sample stack (umpa_hip_stage_sample): the next projection is uploaded + flat-corrected on
+    // `up_stream` into the back buffer while the current one is matched; a match with F_USE_STAGED swaps them
+    hipStream_t up_stream = nullptr;
+    void* d_back_blob = nullptr;                   // back sample frames (float64), same layout as the front ones
+    void* d_raw_blob = nullptr; size_t raw_cap = 0;
+    std::vector<double*> d_sam_back;
+    hipEvent_t ev_staged = nullptr;
+    hipEvent_t ev_read_done[2] = {nullptr, nullptr};   // after the last match that read sample buffer 0 (front at creation) / 1
+    bool read_once[2] = {false, false};
+    bool staged = false;
+    std::vector<hipEvent_t> pending_events;        // of an UMPA_HIP_F_ASYNC match, recycled by umpa_hip_wait
+    FrameDesc* h_desc = nullptr;                   // pinned host copy of the descriptor table (source of the stream-ordered update)
     DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small, b_kern;
     TiledState tiled;                              // scratch of the tiled fast path
     int last_path = 0;
@@ -269,6 +281,38 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
     return rc;
 }
 
+// F_USE_STAGED: the stack uploaded by umpa_hip_stage_sample becomes the sample stack, in stream order on `s`
+int adopt_staged(umpa_hip_model* m, int flags, hipStream_t s)
+{
+    if (!(flags & UMPA_HIP_F_USE_STAGED)) return 0;
+    if (!m->staged) return fail(UMPA_HIP_E_ARG, "UMPA_HIP_F_USE_STAGED without a staged sample stack");
+    HIP_TRY(hipStreamWaitEvent(s, m->ev_staged, 0), UMPA_HIP_E_DEVICE);
+    std::swap(m->d_sam, m->d_sam_back);
+    // the descriptor table is rewritten in stream order: matches already enqueued on `s` still see the old one
+    if (!m->h_desc) HIP_TRY(hipHostMalloc((void**)&m->h_desc, 2 * m->Na * sizeof(FrameDesc), hipHostMallocDefault), UMPA_HIP_E_NOMEM);
+    static_assert(sizeof(FrameDesc) % 8 == 0, "descriptor layout");
+    FrameDesc* h = m->h_desc + (m->d_sam[0] == (double*)m->d_back_blob ? m->Na : 0);   // one slot per buffer parity
+    for (int k = 0; k < m->Na; k++) {
+        h[k].sam = m->d_sam[k]; h[k].ref = m->d_ref[k]; h[k].mask = m->d_mask[k];
+        h[k].H = m->dims[2 * k]; h[k].W = m->dims[2 * k + 1]; h[k].pi = m->pos[2 * k]; h[k].pj = m->pos[2 * k + 1];
+    }
+    HIP_TRY(hipMemcpyAsync(m->d_desc, h, m->Na * sizeof(FrameDesc), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+    m->staged = false;
+    return 0;
+}
+
+// which of the two sample buffers is the front one (the stack the kernels read)
+int front_buffer(const umpa_hip_model* m) { return (m->d_back_blob && m->d_sam[0] == (double*)m->d_back_blob) ? 1 : 0; }
+
+void mark_matched(umpa_hip_model* m, hipStream_t s)
+{
+    if (!m->owns_frames) return;
+    const int q = front_buffer(m);
+    if (!m->ev_read_done[q] && hipEventCreateWithFlags(&m->ev_read_done[q], hipEventDisableTiming) != hipSuccess) { m->ev_read_done[q] = nullptr; return; }
+    (void)hipEventRecord(m->ev_read_done[q], s);
+    m->read_once[q] = true;
+}
+
 } // namespace
 
 extern "C" {
@@ -380,6 +424,87 @@ int umpa_hip_update_frames(umpa_hip_model* m, double* const* sam, double* const*
     return 0;
 }
 
+int umpa_hip_stage_sample(umpa_hip_model* m, const void* const* raw, int raw_dtype,
+                          const double* const* dark, const double* const* flat)
+{
+    if (!m || !raw) return fail(UMPA_HIP_E_ARG, "null argument");
+    if (!m->owns_frames) return fail(UMPA_HIP_E_ARG, "the model borrows device frames: write the next stack there yourself");
+    if (raw_dtype < 0 || raw_dtype > 2) return fail(UMPA_HIP_E_ARG, "raw_dtype %d: 0 float64, 1 float32, 2 uint16", raw_dtype);
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    const size_t esz = raw_dtype == 0 ? 8 : raw_dtype == 1 ? 4 : 2;
+    size_t total = 0;
+    for (int k = 0; k < m->Na; k++) total += (size_t)m->dims[2 * k] * m->dims[2 * k + 1];
+    if (!m->up_stream) HIP_TRY(hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking), UMPA_HIP_E_DEVICE);
+    if (!m->ev_staged) HIP_TRY(hipEventCreateWithFlags(&m->ev_staged, hipEventDisableTiming), UMPA_HIP_E_DEVICE);
+    if (!m->d_back_blob) {
+        HIP_TRY(hipMalloc(&m->d_back_blob, total * sizeof(double)), UMPA_HIP_E_NOMEM);
+        m->d_sam_back.resize(m->Na);
+        size_t off = 0;
+        for (int k = 0; k < m->Na; k++) { m->d_sam_back[k] = (double*)m->d_back_blob + off; off += (size_t)m->dims[2 * k] * m->dims[2 * k + 1]; }
+    }
+    const bool convert = raw_dtype != 0 || dark || flat;
+    if (convert && m->raw_cap < total * esz) {
+        if (m->d_raw_blob) (void)hipFree(m->d_raw_blob);
+        m->d_raw_blob = nullptr; m->raw_cap = 0;
+        HIP_TRY(hipMalloc(&m->d_raw_blob, total * esz), UMPA_HIP_E_NOMEM);
+        m->raw_cap = total * esz;
+    }
+    hipStream_t us = m->up_stream;
+    // the back buffer was the sample stack until the last swap: wait for the last match that read it -- not for the one
+    // that is running on the front buffer now, which is the point of the double buffer
+    const int back = 1 - front_buffer(m);
+    if (m->read_once[back]) HIP_TRY(hipStreamWaitEvent(us, m->ev_read_done[back], 0), UMPA_HIP_E_DEVICE);
+    size_t off = 0;
+    for (int k = 0; k < m->Na; k++) {
+        const size_t n = (size_t)m->dims[2 * k] * m->dims[2 * k + 1];
+        double* out = m->d_sam_back[k];
+        if (!convert) {
+            HIP_TRY(hipMemcpyAsync(out, raw[k], n * 8, hipMemcpyHostToDevice, us), UMPA_HIP_E_DEVICE);
+        } else {
+            char* dr = (char*)m->d_raw_blob + off * esz;
+            HIP_TRY(hipMemcpyAsync(dr, raw[k], n * esz, hipMemcpyHostToDevice, us), UMPA_HIP_E_DEVICE);
+            const double* dk = dark ? dark[k] : nullptr;
+            const double* fl = flat ? flat[k] : nullptr;
+            const unsigned grid = (unsigned)((n + 255) / 256);
+            if (raw_dtype == 0) hipLaunchKernelGGL((umpa::flat_correct_kernel<double>), dim3(grid), dim3(256), 0, us, (const double*)dr, dk, fl, out, n);
+            else if (raw_dtype == 1) hipLaunchKernelGGL((umpa::flat_correct_kernel<float>), dim3(grid), dim3(256), 0, us, (const float*)dr, dk, fl, out, n);
+            else hipLaunchKernelGGL((umpa::flat_correct_kernel<unsigned short>), dim3(grid), dim3(256), 0, us, (const unsigned short*)dr, dk, fl, out, n);
+            HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
+        }
+        off += n;
+    }
+    HIP_TRY(hipEventRecord(m->ev_staged, us), UMPA_HIP_E_DEVICE);
+    m->staged = true;
+    return 0;
+}
+
+int umpa_hip_wait(umpa_hip_model* m)
+{
+    if (!m) return fail(UMPA_HIP_E_ARG, "null model");
+    HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    const hipError_t se = hipStreamSynchronize(m->stream);
+    const hipError_t ce = hipStreamSynchronize(m->copy_stream);
+    for (auto e : m->pending_events) m->event_pool.push_back(e);
+    m->pending_events.clear();
+    if (se != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "match kernels: %s", hipGetErrorString(se));
+    if (ce != hipSuccess) return fail(UMPA_HIP_E_DEVICE, "download of the result maps: %s", hipGetErrorString(ce));
+    return UMPA_HIP_ST_OK;
+}
+
+int umpa_hip_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return fail(UMPA_HIP_E_ARG, "null argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault), UMPA_HIP_E_NOMEM);
+    return 0;
+}
+
+int umpa_hip_host_unregister(void* p)
+{
+    if (!p) return 0;
+    HIP_TRY(hipHostUnregister(p), UMPA_HIP_E_DEVICE);
+    return 0;
+}
+
 void umpa_hip_destroy(umpa_hip_model* m)
 {
     if (!m) return;
@@ -394,6 +519,13 @@ void umpa_hip_destroy(umpa_hip_model* m)
     if (m->d_desc) (void)hipFree(m->d_desc);
     if (m->d_win) (void)hipFree(m->d_win);
     if (m->d_frames_blob) (void)hipFree(m->d_frames_blob);
+    if (m->d_back_blob) (void)hipFree(m->d_back_blob);
+    if (m->d_raw_blob) (void)hipFree(m->d_raw_blob);
+    if (m->h_desc) (void)hipHostFree(m->h_desc);
+    if (m->ev_staged) (void)hipEventDestroy(m->ev_staged);
+    for (int q = 0; q < 2; q++) if (m->ev_read_done[q]) (void)hipEventDestroy(m->ev_read_done[q]);
+    for (auto e : m->pending_events) (void)hipEventDestroy(e);
+    if (m->up_stream) { (void)hipStreamSynchronize(m->up_stream); (void)hipStreamDestroy(m->up_stream); }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     delete m;
@@ -510,11 +642,14 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
     if (flags & UMPA_HIP_F_DEVICE_IO) {
         A.values = values; A.uv = uv; A.err = err; A.cover = covermap;
         A.dbg_d = dbg_d; A.dbg_a = dbg_a; A.dbg_n = dbg_ncalls;
+        if (int rc = adopt_staged(m, flags, (hipStream_t)stream)) return rc;
         if (int rc = run_match(m, A, flags, (hipStream_t)stream)) return rc;
+        mark_matched(m, (hipStream_t)stream);
         return UMPA_HIP_ST_OK;
     }
 
     hipStream_t s = m->stream;
+    if (int rc = adopt_staged(m, flags, s)) return rc;
     if (m->b_values.reserve(n * nparam * sizeof(double)) || m->b_err.reserve(n * sizeof(int)))
         return fail(UMPA_HIP_E_NOMEM, "output buffers (%zu pixels)", n);
     // values and err start from the caller's arrays (zeros in the reference, model.pyx:455,468).  They only matter
@@ -560,8 +695,9 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
         if (p.done) (void)hipEventRecord(p.done, s);
         piece_list.push_back(p);
     };
-    const int pieces = n >= ((size_t)1 << 20) ? 4 : 1;
+    const int pieces = n >= ((size_t)1 << 21) ? 8 : n >= ((size_t)1 << 19) ? 4 : 1;
     if (int rc = run_match(m, A, flags, s, pieces, on_rows)) return rc;
+    mark_matched(m, s);
 
     hipStream_t cs = m->copy_stream;
     hipError_t ce = hipSuccess;
@@ -580,6 +716,10 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
         down(dbg_d, A.dbg_d, sizeof(double), 25, p.lo, p.hi);
         down(dbg_a, A.dbg_a, sizeof(double), 16, p.lo, p.hi);
         down(dbg_ncalls, A.dbg_n, sizeof(int), 1, p.lo, p.hi);
+    }
+    if ((flags & UMPA_HIP_F_ASYNC) && ce == hipSuccess) {          // the caller collects the result with umpa_hip_wait
+        for (const Piece& p : piece_list) if (p.done) m->pending_events.push_back(p.done);
+        return UMPA_HIP_ST_OK;
     }
     if (ce == hipSuccess) ce = hipStreamSynchronize(cs);
     const hipError_t se = hipStreamSynchronize(s);

@@ -355,7 +355,7 @@ class UMPAModelBase:
             # one plane per map: the device writes the result maps directly (no host-side de-interleaving)
             planar = True
             shp = (self.Nparam, N0, N1)
-            values = _lib.pinned_empty(shp, NPDOUBLE, zero=covermap is not None)
+            values = self._alloc(shp, NPDOUBLE, covermap is not None)
         else:
             values = np.zeros(shp, dtype=NPDOUBLE)
 
@@ -365,13 +365,13 @@ class UMPAModelBase:
             uv[:, :, 0] = dxdy[0]
             uv[:, :, 1] = dxdy[1]
         if self._lib.is_hip:                                        # page-locked: downloaded at PCIe rate, chunk by chunk
-            err = _lib.pinned_empty(sh, np.int32, zero=covermap is not None)
+            err = self._alloc(sh, np.int32, covermap is not None)
         else:
             err = np.zeros(sh, dtype=np.int32)
         result = {}
         dd = da = dn = None
         if self.debug:                                              # debug = "ncalls": only the evaluation counts
-            mk = (lambda shape, dt: _lib.pinned_empty(shape, dt, zero=covermap is not None)) if self._lib.is_hip else \
+            mk = (lambda shape, dt: self._alloc(shape, dt, covermap is not None)) if self._lib.is_hip else \
                  (lambda shape, dt: np.zeros(shape, dtype=dt))
             if self.debug != "ncalls":
                 dd = mk(sh + (25,), NPDOUBLE)
@@ -404,9 +404,58 @@ class UMPAModelBase:
         return result
 
     _force = 0
+    _use_staged = False
+    _async = False
+    _out_alloc = None           # hook (shape, dtype, zero) -> array for the result maps (farm.py: shared-memory result slots)
+
+    def _alloc(self, shape, dtype, zero):
+        if self._out_alloc is not None:
+            return self._out_alloc(shape, dtype, zero)
+        return _lib.pinned_empty(shape, dtype, zero=zero)
+
+    def match_async(self, **kw):
+        """``match()`` that returns as soon as the kernels and the downloads are enqueued (HIP only); the maps of the
+        returned dictionary are valid after ``wait()``.  Lets a caller upload the next projection meanwhile."""
+        self._async = True
+        try:
+            return self.match(**kw)
+        finally:
+            self._async = False
+
+    def wait(self):
+        self._lib.check(self._lib.wait(self._handle), "wait")
 
     def _match_flags(self):
-        return self._force
+        f = self._force
+        if self._async:
+            f |= _lib.F_ASYNC
+        if self._use_staged:                                        # one-shot: the staged stack is adopted by this match
+            f |= _lib.F_USE_STAGED
+            self._use_staged = False
+        return f
+
+    def stage_sample(self, raw_frames, dark=None, flat=None):
+        """Upload the NEXT sample stack while the current match is still running (extension; the reference builds a
+        new model per projection, ``umpa_multi.py:149``).  ``raw_frames``: host frames of the model's shapes, float64 /
+        float32 / uint16 (page-locked arrays -- ``_lib.pinned_empty`` -- make this return at once); ``dark`` / ``flat``:
+        device float64 stacks (lists of 2-D HIP tensors) for the fused ``(raw - dark) / flat`` of ``umpa_multi.py:144``.
+        The staged stack becomes the sample stack of the next ``match()``."""
+        if not self._lib.is_hip or hasattr(self._sam[0], "data_ptr"):
+            raise RuntimeError('stage_sample needs a model that owns device copies of host frames.')
+        raw = [np.asarray(x) for x in raw_frames]
+        if [tuple(x.shape) for x in raw] != [tuple(x.shape) for x in self._sam]:
+            raise RuntimeError('stage_sample needs a stack of the shapes the model was built with.')
+        code = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.uint16): 2}.get(raw[0].dtype)
+        if code is None or any(x.dtype != raw[0].dtype for x in raw):
+            raise RuntimeError('raw frames must all be float64, float32 or uint16.')
+        self._check_contiguous(raw)
+        fs = _lib.FrameSet(raw)
+        fd = _lib.FrameSet(list(dark)) if dark is not None else None
+        ff = _lib.FrameSet(list(flat)) if flat is not None else None
+        self._lib.check(self._lib.stage_sample(self._handle, fs.table, code, fd.table if fd else None,
+                                               ff.table if ff else None), "stage_sample")
+        self._staged_keep = (raw, dark, flat)                       # alive until the upload has been consumed
+        self._use_staged = True
 
     # -- properties (model.pyx:625-755)
     @property
