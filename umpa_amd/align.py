@@ -88,11 +88,15 @@ def UMPA_nobias(sams, refs, window=1, shift=3, pos_list=None, mask_list=None, as
     """Dark-field match minus the match of the reference stack against itself, ``dx``/``dy`` repaired with
     threshold ``shift`` (reference ``align.py:63-117``; the bias model keeps the default coordinates, ``:114``)."""
     kw = _model_kwargs(window, shift, pos_list, mask_list)
-    PM = model.UMPAModelDF(sams, refs, **kw)
-    bias = model.UMPAModelDF(refs, refs, **kw)
+    # The reference builds two models (align.py:98-113).  Both matches share the reference stack: one model keeps it
+    # (and the reference-side maps of the tiled path) resident on the GPU, matches it against itself first and then
+    # gets the sample stack swapped in -- same numbers, half the uploads and allocations.
+    PM = model.UMPAModelDF(refs, refs, **kw)
+    res_b = PM.match(num_threads=num_threads, ROI=ROI, quiet=True)
+    bdx, bdy = np.array(res_b['dx']), np.array(res_b['dy'])
+    PM.update_frames(sam_list=sams)
     PM.assign_coordinates = assign_coordinates
     res = PM.match(num_threads=num_threads, ROI=ROI, quiet=True)
-    res_b = bias.match(num_threads=num_threads, ROI=ROI, quiet=True)
-    res['dx'] = correct_bad_pixels(res['dx'] - res_b['dx'], shift)
-    res['dy'] = correct_bad_pixels(res['dy'] - res_b['dy'], shift)
+    res['dx'] = correct_bad_pixels(res['dx'] - bdx, shift)
+    res['dy'] = correct_bad_pixels(res['dy'] - bdy, shift)
     return res

@@ -199,6 +199,16 @@ __device__ __forceinline__ double ld_off(const UMPA_GLOBAL double* base, unsigne
     return *reinterpret_cast<const UMPA_GLOBAL double*>(reinterpret_cast<const UMPA_GLOBAL char*>(base) + byte_off);
 }
 
+// 1/x by v_rcp_f64 and two Newton steps (full double precision for the finite, non-zero determinants met here)
+// instead of the IEEE division sequence (scale, rcp, four FMAs, fmas, fixup)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // NA > 0: the number of frames is a compile-time constant (<= UMPA_KTEMPL) and every map plane is addressable
 // with 32-bit byte offsets: straight-line code, no per-frame tests.  NA == 0: any frame count.
 template <int KIND, int NA>
@@ -256,7 +266,7 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
         // Model.cpp:849-858 with one reciprocal instead of the reference's three divisions by the same
         // determinant and the division by wt (1-ulp level differences; the bar is 1e-5).  The dark-field
         // value v = K/T is only needed for the pixel's final answer: `fit.v` carries K, replay_walk divides once.
-        const double rdet = 1.0 / (t2 * t3 - t6 * t6);
+        const double rdet = fast_rcp(t2 * t3 - t6 * t6);
         const double K = (t2 * t5 - t4 * t6) * rdet;
         const double beta = (t3 * t4 - t5 * t6) * rdet;
         fit.t = beta + K;
