@@ -187,7 +187,7 @@ def main():
     dt = time.perf_counter() - t0
     lib.timing_enable(h, 0)
     kernels = collect_kernels(lib, h)
-    path = {1: "direct", 2: "tiled"}.get(lib.last_path(h), "?")
+    path = {1: "direct", 2: "tiled", 3: "direct-staged"}.get(lib.last_path(h), "?")
 
     step(with_ncalls=True)                                  # untimed: evaluation-count statistics of this dataset
     torch.cuda.synchronize()
@@ -295,7 +295,7 @@ def sharded(args, world, rank, local, dev, backend):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0].item())
     kernels = collect_kernels(lib, h)
-    path = {1: "direct", 2: "tiled"}.get(lib.last_path(h), "?")
+    path = {1: "direct", 2: "tiled", 3: "direct-staged"}.get(lib.last_path(h), "?")
     step(with_ncalls=True)
     torch.cuda.synchronize()
 

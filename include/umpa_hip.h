@@ -60,6 +60,8 @@ extern "C" {
                                         Results are identical with and without. */
 
 #define UMPA_HIP_F_USE_STAGED      32 /* the stack uploaded by umpa_hip_stage_sample becomes the sample stack of this match */
+#define UMPA_HIP_F_FORCE_PLAIN_DIRECT 128 /* with F_FORCE_DIRECT: the plain direct kernel (windows through L1) even where the
+                                             staged one (windows out of LDS) applies; the two give identical results */
 #define UMPA_HIP_F_ASYNC           64 /* host-array call: enqueue the kernels and the downloads (into page-locked arrays) and
                                          return; the arrays are valid after umpa_hip_wait() */
 
@@ -176,7 +178,7 @@ int umpa_hip_timing_read(umpa_hip_model *m, int index, const char **name, double
 /* fp64 fused multiply-adds executed by the collected launches of kernel `index` (counted on the host from the launch
  * geometry; filled in for corr_volume, 0 for kernels that do not report it): the numerator of roofline.fp64_fma */
 int umpa_hip_timing_fma(umpa_hip_model *m, int index, double *fma);
-/* which path the last match_region took: 0 none, 1 direct, 2 tiled */
+/* which path the last match_region took: 0 none, 1 direct (plain), 2 tiled, 3 direct (staged: windows out of LDS) */
 int umpa_hip_last_path(umpa_hip_model *m);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "libumpa_hip.so")
 
 ST_OK, ST_BOUND, ST_DIM, ST_POSITIVE = 1, 2, 4, 8
 F_DEVICE_FRAMES = 1
-F_DEVICE_IO, F_FORCE_DIRECT, F_FORCE_TILED, F_PLANAR, F_REUSE_REF_MAPS, F_USE_STAGED, F_ASYNC = 1, 2, 4, 8, 16, 32, 64
+F_DEVICE_IO, F_FORCE_DIRECT, F_FORCE_TILED, F_PLANAR, F_REUSE_REF_MAPS, F_USE_STAGED, F_ASYNC, F_FORCE_PLAIN_DIRECT = 1, 2, 4, 8, 16, 32, 64, 128
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

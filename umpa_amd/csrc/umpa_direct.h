@@ -61,7 +61,7 @@ __device__ __forceinline__ FrameDesc load_frame(const FrameDesc* frames, int k)
 
 __device__ __forceinline__ double pair_weight(double a, double b)   // Utils.cpp:125-130
 {
-    return a * b / (a + b + 1e-8);
+    return a * b * fast_rcp(a + b + 1e-8);       // one division per window element and frame: the reciprocal is what the masked kernels spend their time on
 }
 
 #define UMPA_BLUR_HALF 8                                   // Model.h:7 KERNEL_WINDOW_SIZE
@@ -269,6 +269,207 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
         const int st = eval_direct<KIND, MASK, NWC>(m, i, j, w.req_i, w.req_j, c, fit, kern, A.kern_stride);
         walk_feed(w, memo, st, c, fit, m.call_cap);
     }
+    double nb[16];
+    walk_finish(w, memo, m.subpx, nb);
+    store_pixel(A, px, KIND, w, memo, nb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The general path with the windows served from LDS ("staged" direct kernel).
+//
+// match_direct reads every window element of every evaluation through the L1/TA path, which is what bounds it
+// (2.7 TB per C2 match at 51 of 64 B/clk/CU).  All windows a workgroup of 64 x 4 pixels can ever ask for lie in a
+// fixed footprint: its pixel box widened by Nw for the stack whose window does not move and by Nw + max_shift - 1
+// for the one that does.  Here the workgroup runs the walk in lockstep: for every round of requests it goes through
+// the frames, stages the footprint of frame k (coalesced loads, once for all 256 lanes), and every lane sums its
+// own two windows out of LDS -- the same terms in the same order as eval_direct, so the results are identical.
+// Masks, per-frame positions and shapes, both coordinate conventions and steps work as there; the kernel-dark-field
+// model and footprints that do not fit LDS (large steps) stay on match_direct.
+// ------------------------------------------------------------------------------------------------
+#define UMPA_STAGED_BX 64
+#define UMPA_STAGED_BY 4
+#define UMPA_STAGED_THREADS (UMPA_STAGED_BX * UMPA_STAGED_BY)
+#define UMPA_STAGED_TAIL 24          // fewer walking lanes than this (of 256): they finish without staging
+#define UMPA_STAGED_NR 8             // a footprint has at most NR * BY = 32 rows ...
+#define UMPA_STAGED_NC 2             // ... and NC * BX = 128 columns (staged_geometry sends anything larger to match_direct)
+
+struct StagedGeom {
+    int hq, hr, hm;                  // halo of the sample / reference / mask footprint around the pixel box
+    int rowsQ, colsQ, rowsR, colsR, rowsM, colsM;
+    int offR, offM, offW;            // LDS offsets (doubles) of the reference and mask footprints (sample at 0) and of the window
+};
+
+template <int KIND, bool MASK, int NWC>
+__global__ void __launch_bounds__(UMPA_STAGED_THREADS)
+match_staged_kernel(ModelDev m, RegionArgs A, int nbx, int nby, StagedGeom G)
+{
+    __shared__ double memo_lds[25 * UMPA_STAGED_THREADS];
+    extern __shared__ __attribute__((aligned(16))) char staged_raw[];
+    double* fq = reinterpret_cast<double*>(staged_raw);
+    double* fr = fq + G.offR;
+    double* fm = fq + G.offM;
+    double* wl = fq + G.offW;                                        // the window: every lane reads the same weight (LDS broadcast)
+
+    const int lin = xcd_band_remap(blockIdx.x, nbx * nby);
+    if (lin >= nbx * nby) return;                                    // whole workgroup
+    const int bx = lin % nbx, by = lin / nbx;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int xj = bx * UMPA_STAGED_BX + tx, xi = by * UMPA_STAGED_BY + ty;
+    const size_t px = (size_t)xi * A.N1 + xj;
+    bool active = xi < A.N0 && xj < A.N1;
+    if (active && A.cover && gp(A.cover)[px] < A.thr) active = false;   // model.pyx:480-481: skipped pixels keep their zeros
+    const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
+    const int gi0 = A.org0 + A.step0 * (by * UMPA_STAGED_BY), gj0 = A.org1 + A.step1 * (bx * UMPA_STAGED_BX);   // box origin
+    const LdsMemo<UMPA_STAGED_THREADS> memo = {memo_lds + ty * UMPA_STAGED_BX + tx};
+    const int Nw = NWC > 0 ? NWC : m.Nw, S = 2 * Nw + 1, pad = m.padding, ms = m.ms;
+
+    for (int q = ty * UMPA_STAGED_BX + tx; q < S * S; q += UMPA_STAGED_THREADS) wl[q] = gp(m.win)[q];
+
+    Walk w;
+    walk_begin(w, memo, (active && A.uv) ? gp(A.uv)[2 * px] : 0.0, (active && A.uv) ? gp(A.uv)[2 * px + 1] : 0.0);
+    if (!active) w.phase = PH_DONE;
+
+    // Staged rounds while a fair share of the workgroup is still walking; the few long walks left over (a round costs
+    // the same for 1 lane as for 256) finish on their own through eval_direct -- same terms, same order, same numbers.
+    while (__syncthreads_count(w.phase < PH_FIT) >= UMPA_STAGED_TAIL) {
+        const bool ev = w.phase < PH_FIT;
+        const int si = w.req_i, sj = w.req_j;
+        int st = UMPA_ST_OK;                                         // Model.cpp:372-399 / :654-681
+        if (si <= -ms || si >= ms) st = UMPA_ST_BOUND;
+        else if (sj <= -ms) st = UMPA_ST_BOUND | UMPA_ST_DIM;
+        else if (sj >= ms) st = UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
+        const bool sum = ev && st == UMPA_ST_OK;
+        int ri = i, rj = j, qi = i, qj = j;                          // Model.cpp:408-421 / :688-701
+        if (m.ref_mode) { qi -= si; qj -= sj; } else { ri += si; rj += sj; }
+        // window origins inside the staged footprints
+        const int q0 = (qi - Nw - (gi0 - G.hq)) * G.colsQ + (qj - Nw - (gj0 - G.hq));
+        const int r0 = (ri - Nw - (gi0 - G.hr)) * G.colsR + (rj - Nw - (gj0 - G.hr));
+        const int mq0 = (qi - Nw - (gi0 - G.hm)) * G.colsM + (qj - Nw - (gj0 - G.hm));
+        const int mr0 = (ri - Nw - (gi0 - G.hm)) * G.colsM + (rj - Nw - (gj0 - G.hm));
+        double t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+        double wt = MASK ? 0.0 : (double)m.Na;                       // Model.cpp:425,:711 / :463,:777
+
+        // ---- footprints of frame k: loaded into registers one frame ahead (the loads fly while frame k-1 is summed),
+        // written to LDS when that is done.  Frame coordinates = image coordinates - position, clamped at the frame
+        // edges: what is clamped is never read by a lane the frame contributes to.  Thread (tx, ty) owns the elements
+        // (ty + 4 n, tx + 64 n').
+        double vq[UMPA_STAGED_NR][UMPA_STAGED_NC], vr[UMPA_STAGED_NR][UMPA_STAGED_NC], vm[MASK ? UMPA_STAGED_NR : 1][UMPA_STAGED_NC];
+        auto fetch = [&](int k) {
+            const FrameDesc f = load_frame(m.frames, k);
+            const int fi0 = gi0 - f.pi, fj0 = gj0 - f.pj;
+#pragma unroll
+            for (int nr = 0; nr < UMPA_STAGED_NR; nr++) {
+                const int r = ty + nr * UMPA_STAGED_BY;
+                const size_t rowq = (size_t)min(max(fi0 - G.hq + r, 0), f.H - 1) * f.W;
+                const size_t rowr = (size_t)min(max(fi0 - G.hr + r, 0), f.H - 1) * f.W;
+                const size_t rowm = (size_t)min(max(fi0 - G.hm + r, 0), f.H - 1) * f.W;
+#pragma unroll
+                for (int nc = 0; nc < UMPA_STAGED_NC; nc++) {
+                    const int c = tx + nc * UMPA_STAGED_BX;
+                    vq[nr][nc] = (r < G.rowsQ && c < G.colsQ) ? gp(f.sam)[rowq + min(max(fj0 - G.hq + c, 0), f.W - 1)] : 0.0;
+                    vr[nr][nc] = (r < G.rowsR && c < G.colsR) ? gp(f.ref)[rowr + min(max(fj0 - G.hr + c, 0), f.W - 1)] : 0.0;
+                    if (MASK) vm[nr][nc] = (r < G.rowsM && c < G.colsM) ? gp(f.mask)[rowm + min(max(fj0 - G.hm + c, 0), f.W - 1)] : 0.0;
+                }
+            }
+        };
+        auto deposit = [&]() {
+#pragma unroll
+            for (int nr = 0; nr < UMPA_STAGED_NR; nr++) {
+                const int r = ty + nr * UMPA_STAGED_BY;
+#pragma unroll
+                for (int nc = 0; nc < UMPA_STAGED_NC; nc++) {
+                    const int c = tx + nc * UMPA_STAGED_BX;
+                    if (r < G.rowsQ && c < G.colsQ) fq[r * G.colsQ + c] = vq[nr][nc];
+                    if (r < G.rowsR && c < G.colsR) fr[r * G.colsR + c] = vr[nr][nc];
+                    if (MASK && r < G.rowsM && c < G.colsM) fm[r * G.colsM + c] = vm[nr][nc];
+                }
+            }
+        };
+        fetch(0);
+        for (int k = 0; k < m.Na; k++) {
+            const FrameDesc f = load_frame(m.frames, k);
+            deposit();
+            if (k + 1 < m.Na) fetch(k + 1);
+            __syncthreads();
+            const int li = i - f.pi, lj = j - f.pj;                  // Model.cpp:430-433 / :716-719
+            if (sum && !(li - pad < 0 || li + pad > f.H || lj - pad < 0 || lj + pad > f.W)) {
+                const double* __restrict__ Q = fq + q0;
+                const double* __restrict__ R = fr + r0;
+                const double* __restrict__ MQ = fm + mq0;
+                const double* __restrict__ MR = fm + mr0;
+                double s2 = 0, s4 = 0, s6 = 0, sm = 0;
+                // one window element: the arithmetic and the order of Model.cpp:746-772 (and :813-841 with masks)
+                auto term = [&](double wv, double r, double q, double mr, double mq) {
+                    if (MASK) {
+                        if (KIND == 1) sm += wv * r;                 // the ref mean is never mask-weighted (Model.cpp:804)
+                        wv *= pair_weight(mr, mq);
+                        wt += wv;
+                        s2 += wv;
+                    }
+                    const double wq = wv * q, wr = wv * r;
+                    t1 += wq * q;
+                    t3 += wr * r;
+                    t5 += wr * q;
+                    if (KIND == 1) { s4 += wq; s6 += wr; }
+                };
+                // a window row at a time: all its LDS reads are issued before the first term is summed (an in-order
+                // wave would otherwise pay the LDS latency once per element)
+                constexpr int CH = NWC > 0 ? 2 * NWC + 1 : 8;
+                for (int a = 0; a < S; a++) {
+                    const double* wrow = wl + a * S;
+                    const int oq = a * G.colsQ, orr = a * G.colsR, om = a * G.colsM;
+                    for (int b0 = 0; b0 < S; b0 += CH) {
+                        double wv[CH], rv[CH], qv[CH], mrv[CH], mqv[CH];
+#pragma unroll
+                        for (int b = 0; b < CH; b++) {
+                            const bool in = NWC > 0 || b0 + b < S;
+                            wv[b] = in ? wrow[b0 + b] : 0.0;
+                            rv[b] = in ? R[orr + b0 + b] : 0.0;
+                            qv[b] = in ? Q[oq + b0 + b] : 0.0;
+                            mrv[b] = (MASK && in) ? MR[om + b0 + b] : 0.0;
+                            mqv[b] = (MASK && in) ? MQ[om + b0 + b] : 0.0;
+                        }
+#pragma unroll
+                        for (int b = 0; b < CH; b++)
+                            if (NWC > 0 || b0 + b < S) term(wv[b], rv[b], qv[b], mrv[b], mqv[b]);
+                    }
+                }
+                if (KIND == 1) {                                     // Model.cpp:739,:770-772 / :808,:843-845
+                    const double mean = (MASK ? sm : s6) / m.win_sum;
+                    t2 += MASK ? mean * mean * s2 : mean * mean;
+                    t4 += mean * s4;
+                    t6 += mean * s6;
+                }
+            }
+            __syncthreads();                                         // footprints free for the next frame
+        }
+        if (ev) {
+            double cost = 0.0;
+            Fit fit = w.live;
+            if (st == UMPA_ST_OK) {
+                if (KIND == 1) {                                     // Model.cpp:849-858
+                    const double det = t2 * t3 - t6 * t6;
+                    const double K = (t2 * t5 - t4 * t6) / det;
+                    const double beta = (t3 * t4 - t5 * t6) / det;
+                    fit.t = beta + K;
+                    fit.v = K / fit.t;
+                    cost = (t1 + beta * beta * t2 + K * K * t3 - 2 * beta * t4 - 2 * K * t5 + 2 * beta * K * t6) / wt;
+                } else {                                             // Model.cpp:502-505
+                    fit.t = t5 / t3;
+                    fit.v = 0.0;
+                    cost = (t1 - t5 * fit.t) / wt;
+                }
+            }
+            walk_feed(w, memo, st, cost, fit, m.call_cap);
+        }
+    }
+    while (w.phase < PH_FIT) {
+        double c = 0.0;
+        Fit fit = w.live;
+        const int st = eval_direct<KIND, MASK, NWC>(m, i, j, w.req_i, w.req_j, c, fit);
+        walk_feed(w, memo, st, c, fit, m.call_cap);
+    }
+    if (!active) return;
     double nb[16];
     walk_finish(w, memo, m.subpx, nb);
     store_pixel(A, px, KIND, w, memo, nb);

@@ -109,8 +109,8 @@ struct umpa_hip_model {
 
 namespace {
 
-const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk"};
-enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4 };
+const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk", "match_staged"};
+enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4, KN_STAGED = 5 };
 
 hipEvent_t get_event(umpa_hip_model* m)
 {
@@ -202,10 +202,88 @@ void launch_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
     launch_direct_nw<KIND, MASK, 0>(m, A, s);
 }
 
-int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s)
+// Footprints of the staged general kernel for this region; false if they do not fit beside the walk memo
+bool staged_geometry(const umpa_hip_model* m, const RegionArgs& A, StagedGeom& G, size_t& lds_bytes)
+{
+    const int boxr = (UMPA_STAGED_BY - 1) * A.step0 + 1, boxc = (UMPA_STAGED_BX - 1) * A.step1 + 1;
+    const int wide = m->Nw + std::max(m->ms - 1, 0);
+    G.hq = m->ref_mode ? wide : m->Nw;                                // the sample window moves in 'ref' mode (Model.cpp:688-701)
+    G.hr = m->ref_mode ? m->Nw : wide;
+    G.hm = wide;
+    G.rowsQ = boxr + 2 * G.hq; G.colsQ = boxc + 2 * G.hq;
+    G.rowsR = boxr + 2 * G.hr; G.colsR = boxc + 2 * G.hr;
+    G.rowsM = m->has_mask ? boxr + 2 * G.hm : 0; G.colsM = m->has_mask ? boxc + 2 * G.hm : 0;
+    G.offR = (G.rowsQ * G.colsQ + 1) & ~1;
+    G.offM = (G.offR + G.rowsR * G.colsR + 1) & ~1;
+    G.offW = (G.offM + G.rowsM * G.colsM + 1) & ~1;
+    const int S = 2 * m->Nw + 1;
+    lds_bytes = (size_t)(G.offW + S * S + 2) * sizeof(double);
+    const size_t memo = (size_t)25 * UMPA_STAGED_THREADS * sizeof(double);
+    const int maxr = UMPA_STAGED_NR * UMPA_STAGED_BY, maxc = UMPA_STAGED_NC * UMPA_STAGED_BX;
+    if (std::max(G.rowsQ, std::max(G.rowsR, G.rowsM)) > maxr || std::max(G.colsQ, std::max(G.colsR, G.colsM)) > maxc) return false;
+    return lds_bytes + memo <= (size_t)UMPA_LDS_BUDGET - 1024;
+}
+
+template <int KIND, bool MASK, int NWC>
+hipError_t launch_staged_nw(umpa_hip_model* m, const RegionArgs& A, const StagedGeom& G, size_t lds_bytes, hipStream_t s)
+{
+    static bool attr_set[64] = {};
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    {
+        std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+        if (!attr_set[devid & 63]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&match_staged_kernel<KIND, MASK, NWC>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(UMPA_LDS_BUDGET - 25 * UMPA_STAGED_THREADS * sizeof(double) - 1024));
+            if (e != hipSuccess) return e;
+            attr_set[devid & 63] = true;
+        }
+    }
+    const int nbx = (A.N1 + UMPA_STAGED_BX - 1) / UMPA_STAGED_BX, nby = (A.N0 + UMPA_STAGED_BY - 1) / UMPA_STAGED_BY;
+    const int grid = ((nbx * nby + 7) / 8) * 8;
+    ScopedTimer t(m, s, KN_STAGED);
+    hipLaunchKernelGGL((match_staged_kernel<KIND, MASK, NWC>), dim3(grid), dim3(UMPA_STAGED_BX, UMPA_STAGED_BY), lds_bytes, s,
+                       m->dev(), A, nbx, nby, G);
+    return hipGetLastError();
+}
+
+template <int KIND, bool MASK>
+hipError_t launch_staged(umpa_hip_model* m, const RegionArgs& A, const StagedGeom& G, size_t lds_bytes, hipStream_t s)
+{
+    switch (m->Nw) {
+    case 1: return launch_staged_nw<KIND, MASK, 1>(m, A, G, lds_bytes, s);
+    case 2: return launch_staged_nw<KIND, MASK, 2>(m, A, G, lds_bytes, s);
+    case 3: return launch_staged_nw<KIND, MASK, 3>(m, A, G, lds_bytes, s);
+    case 4: return launch_staged_nw<KIND, MASK, 4>(m, A, G, lds_bytes, s);
+    case 5: return launch_staged_nw<KIND, MASK, 5>(m, A, G, lds_bytes, s);
+    case 6: return launch_staged_nw<KIND, MASK, 6>(m, A, G, lds_bytes, s);
+    case 7: return launch_staged_nw<KIND, MASK, 7>(m, A, G, lds_bytes, s);
+    case 8: return launch_staged_nw<KIND, MASK, 8>(m, A, G, lds_bytes, s);
+    default: return launch_staged_nw<KIND, MASK, 0>(m, A, G, lds_bytes, s);
+    }
+}
+
+int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags = 0)
 {
     RegionArgs A = A0;
     A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
+    // the staged kernel (windows out of LDS) for regions of more than a few pixels whose footprints fit; the plain one
+    // (windows through L1) for the kernel-dark-field model, single pixels, large steps, or on request
+    static const bool no_staged = getenv("UMPA_HIP_NO_STAGED") != nullptr;
+    StagedGeom G;
+    size_t lds_bytes = 0;
+    // (with masks the staged kernel is the slower one -- three footprints leave room for one workgroup per CU and the
+    // weights make the summation VALU-bound: 225 against 152 ms on C2 -- so masked models stay on match_direct)
+    if (m->kind != UMPA_HIP_KIND_DFKERNEL && !m->has_mask && !no_staged && !(flags & UMPA_HIP_F_FORCE_PLAIN_DIRECT) &&
+        (size_t)A.N0 * A.N1 >= 64 && staged_geometry(m, A, G, lds_bytes)) {
+        hipError_t e;
+        if (m->kind == UMPA_HIP_KIND_NODF) e = m->has_mask ? launch_staged<0, true>(m, A, G, lds_bytes, s) : launch_staged<0, false>(m, A, G, lds_bytes, s);
+        else e = m->has_mask ? launch_staged<1, true>(m, A, G, lds_bytes, s) : launch_staged<1, false>(m, A, G, lds_bytes, s);
+        if (e != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "staged kernel: %s", hipGetErrorString(e));
+        m->last_path = 3;
+        return 0;
+    }
     if (m->kind == UMPA_HIP_KIND_DFKERNEL) {
         // every pixel carries its own 17x17 blur kernel (Model.cpp:88-117): 289 doubles of scratch per pixel,
         // so the region is matched in row chunks whose scratch stays below 1 GiB
@@ -276,7 +354,7 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
         m->last_path = 2;
         return 0;
     }
-    const int rc = run_direct(m, A, s);
+    const int rc = run_direct(m, A, s, flags);
     if (rc == 0 && on_rows) on_rows(0, A.N0);
     return rc;
 }

@@ -199,16 +199,6 @@ __device__ __forceinline__ double ld_off(const UMPA_GLOBAL double* base, unsigne
     return *reinterpret_cast<const UMPA_GLOBAL double*>(reinterpret_cast<const UMPA_GLOBAL char*>(base) + byte_off);
 }
 
-// 1/x by v_rcp_f64 and two Newton steps (full double precision for the finite, non-zero determinants met here)
-// instead of the IEEE division sequence (scale, rcp, four FMAs, fmas, fixup)
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
 // NA > 0: the number of frames is a compile-time constant (<= UMPA_KTEMPL) and every map plane is addressable
 // with 32-bit byte offsets: straight-line code, no per-frame tests.  NA == 0: any frame count.
 template <int KIND, int NA>

@@ -31,6 +31,16 @@ __device__ __forceinline__ const UMPA_GLOBAL T* gp(const T* p) { return (const U
 template <class T>
 __device__ __forceinline__ UMPA_GLOBAL T* gpw(T* p) { return (UMPA_GLOBAL T*)p; }
 
+// 1/x by v_rcp_f64 and two Newton steps (full double precision for the finite, non-zero arguments met here)
+// instead of the IEEE division sequence (scale, rcp, four FMAs, fmas, fixup)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 struct Fit { double t, v; };       // the CostArgs payload (Model.h:29-52)
 
 enum Phase { PH_CENTRE = 0, PH_LO = 1, PH_HI = 2, PH_GATHER = 3, PH_FIT = 4, PH_DONE = 5 };
