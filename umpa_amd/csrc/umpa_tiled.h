@@ -51,7 +51,10 @@ struct PrepCfg {
     static constexpr int T = UMPA_TILE, S = 2 * NW + 1, Q = T + 2 * NW, QP = Q | 1, NT = 256, CB = 8;
     static constexpr int RAW = Q * QP;                    // one transposed raw patch [c][r]
     static constexpr int HPL = T * QP;                    // one H-filtered plane [c < T][r < Q]
-    static constexpr size_t LDS = (size_t)(2 * RAW + 4 * HPL) * sizeof(double);
+    // the sample and the reference patch of a frame go through the same LDS one after the other: one raw patch and
+    // its two H-filtered planes (values, squares) -- 36 KB at Nw = 5, 41 KB at Nw = 7: three to four workgroups per CU
+    // (with both stacks resident the C3 window needed 83 KB, one workgroup per CU, and ran at a third of the HBM rate)
+    static constexpr size_t LDS = (size_t)(RAW + 2 * HPL) * sizeof(double);
 };
 
 template <int KIND, int NW>
@@ -63,9 +66,8 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
     const bool do_ref = (sides & 2) != 0;
     using C = PrepCfg<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* rawS = reinterpret_cast<double*>(smem_raw);
-    double* rawR = rawS + C::RAW;
-    double* hpl = rawR + C::RAW;                           // 4 planes: Hs, Hss, Hr, Hrr
+    double* raw = reinterpret_cast<double*>(smem_raw);
+    double* hpl = raw + C::RAW;                            // 2 planes: H-filtered values, H-filtered squares
 
     const int lin = xcd_band_remap(blockIdx.x, ntx * nty);
     if (lin >= ntx * nty) return;
@@ -75,13 +77,12 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
     const int tid = threadIdx.x;
     const size_t plane = (size_t)M.H * M.W;
 
-    // V-stage ownership: item = (ptype, rb, c), c fastest.  ptype 0: Hs, 1: Hss, 2: Hr, 3: Hrr.
-    // 4 ptypes x 4 row blocks x 32 columns = 512 items, two per thread (wave-uniform ptype).
-    double acc[2][C::CB], acc2[2][C::CB];
+    // V-stage ownership: item = (sq, rb, c), c fastest: 2 planes x 4 row blocks x 32 columns = 256 items, one per
+    // thread and stack (wave-uniform sq).  acc[st]: sums over the frames for stack st (0 sample, 1 reference).
+    const int vc = tid & 31, vrb = (tid >> 5) & 3, vsq = tid >> 7;
+    double acc[2][C::CB], acc2[C::CB];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int o = 0; o < C::CB; o++) { acc[q][o] = 0.0; acc2[q][o] = 0.0; }
+    for (int o = 0; o < C::CB; o++) { acc[0][o] = acc[1][o] = 0.0; acc2[o] = 0.0; }
 
     // staging slots of this thread: compile-time count, so the frame k+1 can wait in registers while frame k is filtered
     constexpr int NS = (C::Q * C::Q + C::NT - 1) / C::NT;
@@ -103,75 +104,70 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
     };
     fetch(0);
     for (int k = 0; k < m.Na; k++) {
-        __syncthreads();
-        // stage the raw patches, transposed; the global reads (issued one frame ahead) are coalesced along columns
 #pragma unroll
-        for (int n = 0; n < NS; n++)
-            if (s_lds[n] >= 0) { rawS[s_lds[n]] = ps[n]; rawR[s_lds[n]] = pr[n]; }
-        if (k + 1 < m.Na) fetch(k + 1);
-        __syncthreads();
-        // H stage (along columns): items (which, cb, r), r fastest: 2 x 4 x Q
-        for (int it = tid; it < (do_ref ? 2 : 1) * 4 * C::Q; it += C::NT) {
-            const int r = it % C::Q, rest = it / C::Q, cb = rest & 3, which = rest >> 2;
-            const double* src = (which ? rawR : rawS) + (cb * C::CB) * C::QP + r;
-            double lin_[C::CB], sq_[C::CB];
+        for (int st = 0; st < 2; st++) {                              // 0: sample patch, 1: reference patch
+            if (st == 1 && !do_ref) break;
+            __syncthreads();                                          // every reader of the LDS region is done
+            // stage the raw patch, transposed; the global reads (issued one frame ahead) are coalesced along columns
 #pragma unroll
-            for (int o = 0; o < C::CB; o++) { lin_[o] = 0.0; sq_[o] = 0.0; }
+            for (int n = 0; n < NS; n++)
+                if (s_lds[n] >= 0) raw[s_lds[n]] = st ? pr[n] : ps[n];
+            if (st == (do_ref ? 1 : 0) && k + 1 < m.Na) fetch(k + 1);  // both patches of frame k are out of the registers
+            __syncthreads();
+            // H stage (along columns): items (cb, r), r fastest: 4 x Q <= 256
+            if (tid < 4 * C::Q) {
+                const int r = tid % C::Q, cb = tid / C::Q;
+                const double* src = raw + (cb * C::CB) * C::QP + r;
+                double lin_[C::CB], sq_[C::CB];
 #pragma unroll
-            for (int t = 0; t < C::CB + C::S - 1; t++) {
-                const double v = src[t * C::QP];
-                const double v2 = v * v;
+                for (int o = 0; o < C::CB; o++) { lin_[o] = 0.0; sq_[o] = 0.0; }
+#pragma unroll
+                for (int t = 0; t < C::CB + C::S - 1; t++) {
+                    const double v = src[t * C::QP];
+                    const double v2 = v * v;
+#pragma unroll
+                    for (int o = 0; o < C::CB; o++) {
+                        const int tap = t - o;
+                        if (tap >= 0 && tap < C::S) { lin_[o] = fma(sep.hc[tap], v, lin_[o]); sq_[o] = fma(sep.hc[tap], v2, sq_[o]); }
+                    }
+                }
+                double* dl = hpl + (cb * C::CB) * C::QP + r;
+                double* dq = dl + C::HPL;
+#pragma unroll
+                for (int o = 0; o < C::CB; o++) { dl[o * C::QP] = lin_[o]; dq[o * C::QP] = sq_[o]; }
+            }
+            __syncthreads();
+            // V stage (along rows): vsq = 0 the windowed values (W[s_k] / W[r_k]), vsq = 1 the windowed squares
+            if (!(KIND == 0 && vsq == 0)) {                           // NoDF needs only the squares
+                double out[C::CB];
+                fir_block<NW, C::CB>(hpl + vsq * C::HPL + vc * C::QP + vrb * C::CB, 1, sep.hr, out);
+                const int gc = c0 + vc;
 #pragma unroll
                 for (int o = 0; o < C::CB; o++) {
-                    const int tap = t - o;
-                    if (tap >= 0 && tap < C::S) { lin_[o] = fma(sep.hc[tap], v, lin_[o]); sq_[o] = fma(sep.hc[tap], v2, sq_[o]); }
+                    const int gr = r0 + vrb * C::CB + o;
+                    const bool inside = gr < M.H - NW && gc < M.W - NW;
+                    if (vsq == 1) acc[st][o] += out[o];               // t1 / t3
+                    else if (st == 0) { if (inside) gpw(M.WS)[k * plane + (size_t)gr * M.W + gc] = out[o]; }
+                    else {
+                        const double mean = out[o] / m.win_sum;       // Model.cpp:739
+                        if (inside) gpw(M.MR)[k * plane + (size_t)gr * M.W + gc] = mean;
+                        acc[1][o] += mean * mean;                     // t2, Model.cpp:770
+                        acc2[o] += mean * out[o];                     // t6, Model.cpp:772
+                    }
                 }
-            }
-            double* dl = hpl + (which ? 2 : 0) * C::HPL + (cb * C::CB) * C::QP + r;
-            double* dq = dl + C::HPL;
-#pragma unroll
-            for (int o = 0; o < C::CB; o++) { dl[o * C::QP] = lin_[o]; dq[o * C::QP] = sq_[o]; }
-        }
-        __syncthreads();
-        // V stage (along rows)
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int it = tid + q * C::NT;
-            const int c = it & 31, rb = (it >> 5) & 3, ptype = it >> 7;
-            if (q == 1 && !do_ref) continue;                             // q = 1 holds the two reference planes
-            if (KIND == 0 && (ptype == 0 || ptype == 2)) continue;       // NoDF needs only the squares
-            double out[C::CB];
-            fir_block<NW, C::CB>(hpl + ptype * C::HPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
-            const int gc = c0 + c;
-#pragma unroll
-            for (int o = 0; o < C::CB; o++) {
-                const int gr = r0 + rb * C::CB + o;
-                const bool inside = gr < M.H - NW && gc < M.W - NW;
-                if (ptype == 0) { if (inside) gpw(M.WS)[k * plane + (size_t)gr * M.W + gc] = out[o]; }
-                else if (ptype == 2) {
-                    const double mean = out[o] / m.win_sum;                // Model.cpp:739
-                    if (inside) gpw(M.MR)[k * plane + (size_t)gr * M.W + gc] = mean;
-                    acc[q][o] += mean * mean;                             // t2, Model.cpp:770
-                    acc2[q][o] += mean * out[o];                          // t6, Model.cpp:772
-                } else acc[q][o] += out[o];                               // t1 / t3
             }
         }
     }
+    const int gc = c0 + vc;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int it = tid + q * C::NT;
-        const int c = it & 31, rb = (it >> 5) & 3, ptype = it >> 7;
-        const int gc = c0 + c;
-        if (q == 1 && !do_ref) continue;
-#pragma unroll
-        for (int o = 0; o < C::CB; o++) {
-            const int gr = r0 + rb * C::CB + o;
-            if (gr >= M.H - NW || gc >= M.W - NW) continue;
-            const size_t g = (size_t)gr * M.W + gc;
-            if (ptype == 1) gpw(M.SamSq)[g] = acc[q][o];
-            else if (ptype == 3) gpw(M.RefSq)[g] = acc[q][o];
-            else if (ptype == 2 && KIND == 1) { gpw(M.RefM2)[g] = acc[q][o]; gpw(M.RefM6)[g] = acc2[q][o]; }
-        }
+    for (int o = 0; o < C::CB; o++) {
+        const int gr = r0 + vrb * C::CB + o;
+        if (gr >= M.H - NW || gc >= M.W - NW) continue;
+        const size_t g = (size_t)gr * M.W + gc;
+        if (vsq == 1) {
+            gpw(M.SamSq)[g] = acc[0][o];
+            if (do_ref) gpw(M.RefSq)[g] = acc[1][o];
+        } else if (KIND == 1 && do_ref) { gpw(M.RefM2)[g] = acc[1][o]; gpw(M.RefM6)[g] = acc2[o]; }
     }
 }
 
