@@ -222,7 +222,7 @@ __device__ __forceinline__ void store_pixel(const RegionArgs& A, size_t px, int 
     if (A.uv) { gpw(A.uv)[2 * px] = w.uv0; gpw(A.uv)[2 * px + 1] = w.uv1; }
     gpw(A.err)[px] = w.status & UMPA_ST_OK;
     if (A.dbg_n) gpw(A.dbg_n)[px] = w.n;
-    if (A.dbg_d) for (int q = 0; q < 25; q++) gpw(A.dbg_d)[px * 25 + q] = memo[q];
+    if (A.dbg_d) for (int q = 0; q < 25; q++) gpw(A.dbg_d)[px * 25 + q] = walk_memo_cell(w, memo, q);
     if (A.dbg_a) for (int q = 0; q < 16; q++) gpw(A.dbg_a)[px * 16 + q] = nb[q];
 }
 

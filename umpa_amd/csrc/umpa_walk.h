@@ -45,9 +45,15 @@ struct Fit { double t, v; };       // the CostArgs payload (Model.h:29-52)
 
 enum Phase { PH_CENTRE = 0, PH_LO = 1, PH_HI = 2, PH_GATHER = 3, PH_FIT = 4, PH_DONE = 5 };
 
-// The 5x5 memo lives in LDS, one column per lane ([cell][lane]): the walk indexes it with
-// run-time cell numbers, which would push a per-lane array into scratch memory (HBM-backed,
-// ~10x the latency).  25 cells x 256 lanes x 8 B = 50 KiB per workgroup, conflict-free.
+// The 5x5 memo of the reference (Optim.cpp:252: the costs known around the current centre, -1 = unknown) is kept
+// here as two things:
+//   * `Walk::known`, a 25-bit mask (bit 5r+c: cell (r,c) of the neighbourhood, centre (2,2)): what the reference
+//     tests with `d[..] < 0`.  Moving the centre shifts the mask (cells that scroll in are unknown), a hard restart
+//     clears it -- a few integer instructions instead of the 25 loads and stores of the reference's array shuffle;
+//   * the values, in LDS, one column per lane ([slot][lane]: the walk indexes them with run-time cell numbers, which
+//     would push a per-lane array into scratch memory), addressed as a TORUS: the cost of the absolute shift (x, y)
+//     lives in slot 5 (x mod 5) + (y mod 5).  The 5x5 neighbourhood spans five consecutive values per axis, so this is
+//     a bijection for any centre and nothing ever moves; slots are never initialised (the mask says what is valid).
 template <int STRIDE>
 struct LdsMemo {
     double* p;
@@ -55,7 +61,7 @@ struct LdsMemo {
 };
 
 struct Walk {
-    int ci, cj;        // integer centre of the 5x5 memo
+    int ci, cj;        // integer centre of the 5x5 neighbourhood
     int req_i, req_j;  // shift whose cost is wanted next
     int axis;          // 0: columns (west/east), 1: rows
     int found0, found1;
@@ -64,11 +70,25 @@ struct Walk {
     int g;             // gather: the cell 0..15 being asked for
     unsigned need;     // gather: cells of the 4x4 neighbourhood still unknown (bit g)
     int ip, jp;        // quadrant of the 4x4 neighbourhood
-    double c0;         // cost at the centre (memo cell 12)
+    double c0;         // cost at the centre
     int status;
     Fit live, kept;    // *args and args_copy of Optim.cpp:249,265
     double out, uv0, uv1;
+    unsigned known;    // bit 5r+c: cell (r,c) has been evaluated since it scrolled in
+    int bi, bj;        // (ci - 2) mod 5, (cj - 2) mod 5: torus row / column of cell (0,0)
 };
+
+__device__ __forceinline__ int wrap5(int x) { return x >= 5 ? x - 5 : x; }                  // x in [0, 9]
+__device__ __forceinline__ int mod5(int x) { const int r = x % 5; return r < 0 ? r + 5 : r; }
+// LDS slot of cell (r, c), 0 <= r, c <= 4
+__device__ __forceinline__ int walk_slot(const Walk& w, int r, int c) { return 5 * wrap5(w.bi + r) + wrap5(w.bj + c); }
+
+// minimizer_debug::d as the reference leaves it: the known costs of the 5x5 neighbourhood, -1 elsewhere
+template <class Memo>
+__device__ __forceinline__ double walk_memo_cell(const Walk& w, Memo memo, int q)
+{
+    return (w.known >> q) & 1u ? memo[walk_slot(w, q / 5, q % 5)] : -1.0;
+}
 
 // ---------------------------------------------------------------- sub-pixel fits
 
@@ -161,10 +181,11 @@ __device__ inline double spmin_quad(const double* a, double& px, double& py)
 template <class Memo>
 __device__ inline void walk_begin(Walk& w, Memo memo, double u0, double u1)
 {
-#pragma unroll
-    for (int q = 0; q < 25; q++) memo[q] = -1.0;               // Optim.cpp:252
     w.ci = (int)round(u0);                                      // Optim.cpp:258-259
     w.cj = (int)round(u1);
+    w.bi = mod5(w.ci - 2);
+    w.bj = mod5(w.cj - 2);
+    w.known = 0;                                                // Optim.cpp:252
     w.req_i = w.ci;
     w.req_j = w.cj;
     w.axis = 0;
@@ -181,33 +202,6 @@ __device__ inline void walk_begin(Walk& w, Memo memo, double u0, double u1)
     w.out = 0.0;                                                // `D` is uninitialised in the reference (Model.cpp:566,927)
     w.uv0 = u0;
     w.uv1 = u1;
-}
-
-template <class Memo>
-__device__ inline void memo_shift(Memo d, int axis, int dir)
-{
-    // Optim.cpp:436-470: the centre moved by `dir` along `axis`; cells that scroll in are unknown
-    if (axis) {
-        if (dir > 0) {
-            for (int q = 5; q < 25; q++) d[q - 5] = d[q];
-            for (int q = 20; q < 25; q++) d[q] = -1.0;
-        } else {
-            for (int q = 24; q >= 5; q--) d[q] = d[q - 5];
-            for (int q = 0; q < 5; q++) d[q] = -1.0;
-        }
-    } else {
-        if (dir > 0) {
-            for (int r = 0; r < 5; r++) {
-                for (int c = 0; c < 4; c++) d[5 * r + c] = d[5 * r + c + 1];
-                d[5 * r + 4] = -1.0;
-            }
-        } else {
-            for (int r = 0; r < 5; r++) {
-                for (int c = 4; c > 0; c--) d[5 * r + c] = d[5 * r + c - 1];
-                d[5 * r] = -1.0;
-            }
-        }
-    }
 }
 
 // Deliver the result of the pending request (status `st`, cost `val`, fit parameters `fit`)
@@ -236,35 +230,40 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
     bool cap_test = w.phase == PH_CENTRE;
     bool scan = false;
     if (w.phase == PH_GATHER) {                                 // Optim.cpp:353-378
-        const int r = w.g >> 2, c = w.g & 3;
-        memo[5 * (w.ip + r) + w.jp + c] = val;                  // the `a` entry is this memo cell (Optim.cpp:357-362)
-        if (val < w.c0) {                                       // missed a lower value: hard restart
-            w.ci += w.ip + r - 2;
-            w.cj += w.jp + c - 2;
-            for (int q = 0; q < 25; q++) memo[q] = -1.0;
-            memo[12] = val;
+        const int rr = w.ip + (w.g >> 2), cc = w.jp + (w.g & 3);   // the `a` entry is this cell of the neighbourhood
+        memo[walk_slot(w, rr, cc)] = val;
+        if (val < w.c0) {                                       // missed a lower value: hard restart, centred there
+            const int di = rr - 2, dj = cc - 2;
+            w.ci += di;
+            w.cj += dj;
+            int x = w.bi + di, y = w.bj + dj;                   // in [-2, 6]
+            x += x < 0 ? 5 : 0; y += y < 0 ? 5 : 0;
+            w.bi = wrap5(x); w.bj = wrap5(y);
+            w.known = 1u << 12;                                 // only the new centre (its value sits in its slot already)
             w.c0 = val;
             w.live = w.kept;                                    // stale on purpose (Optim.cpp:373)
             w.found0 = w.found1 = 0;
         } else {
+            w.known |= 1u << (5 * rr + cc);
             w.need &= w.need - 1;
             scan = true;
         }
     } else {
         bool keep;
-        int cell;
+        int r, c;
         if (w.phase == PH_CENTRE) {                             // Optim.cpp:262-265
-            cell = 12;
+            r = 2; c = 2;
             w.c0 = val;
             keep = true;
         } else if (w.phase == PH_LO) {                          // Optim.cpp:287-297
-            cell = w.axis ? 7 : 11;
+            r = w.axis ? 1 : 2; c = w.axis ? 2 : 1;
             keep = !(val > w.c0 + UMPA_TIE);
         } else {                                                // PH_HI, Optim.cpp:320-328
-            cell = w.axis ? 17 : 13;
+            r = w.axis ? 3 : 2; c = w.axis ? 2 : 3;
             keep = !(val > w.c0 - UMPA_TIE);
         }
-        memo[cell] = val;
+        memo[walk_slot(w, r, c)] = val;
+        w.known |= 1u << (5 * r + c);
         if (keep) w.kept = w.live;
     }
 
@@ -275,21 +274,20 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
             return;
         }
         cap_test = true;
-        const int lo = w.axis ? 7 : 11, hi = w.axis ? 17 : 13;
-        const double dlo = memo[lo], dhi = memo[hi];
-        const int unknown = (dlo < -0.5 ? 1 : 0) | (dhi < -0.5 ? 2 : 0);    // both reads in flight before any branch
-        if (unknown & 1) {
+        const int lr = w.axis ? 1 : 2, lc = w.axis ? 2 : 1, hr = w.axis ? 3 : 2, hc = w.axis ? 2 : 3;
+        if (!((w.known >> (5 * lr + lc)) & 1u)) {
             w.phase = PH_LO;
             w.req_i = w.ci - (w.axis ? 1 : 0);
             w.req_j = w.cj - (w.axis ? 0 : 1);
             return;
         }
-        if (unknown) {
+        if (!((w.known >> (5 * hr + hc)) & 1u)) {
             w.phase = PH_HI;
             w.req_i = w.ci + (w.axis ? 1 : 0);
             w.req_j = w.cj + (w.axis ? 0 : 1);
             return;
         }
+        const double dlo = memo[walk_slot(w, lr, lc)], dhi = memo[walk_slot(w, hr, hc)];
         const bool lo_up = dlo > w.c0 + UMPA_TIE;               // Optim.cpp:294,300
         const bool hi_up = dhi > w.c0 - UMPA_TIE;               // Optim.cpp:325,331
         if (lo_up && hi_up) {                                   // Optim.cpp:334-417
@@ -300,16 +298,13 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
                 w.axis ^= 1;
                 continue;
             }
-            w.ip = memo[17] < memo[7] ? 1 : 0;                  // Optim.cpp:344-345
-            w.jp = memo[13] < memo[11] ? 1 : 0;
-            // which cells of the 4x4 neighbourhood are still unknown: nothing but this walk's own
-            // requests changes the memo until the gather ends, so one look is enough
-            const int q0 = 5 * w.ip + w.jp;
-            unsigned need = 0;
-#pragma unroll
-            for (int g = 0; g < 16; g++)
-                if (memo[q0 + 5 * (g >> 2) + (g & 3)] < -0.9) need |= 1u << g;
-            w.need = need;
+            // both axes have a minimum here, so the four neighbours of the centre are known
+            w.ip = memo[walk_slot(w, 3, 2)] < memo[walk_slot(w, 1, 2)] ? 1 : 0;     // Optim.cpp:344-345
+            w.jp = memo[walk_slot(w, 2, 3)] < memo[walk_slot(w, 2, 1)] ? 1 : 0;
+            // which cells of the 4x4 neighbourhood are still unknown: rows ip .. ip+3, columns jp .. jp+3 of the mask
+            const unsigned sub = w.known >> (5 * w.ip + w.jp);
+            const unsigned have = (sub & 0xFu) | ((sub >> 5) & 0xFu) << 4 | ((sub >> 10) & 0xFu) << 8 | ((sub >> 15) & 0xFu) << 12;
+            w.need = ~have & 0xFFFFu;
             scan = true;
         } else {                                                // Optim.cpp:420-474
             w.uv0 = w.ci;
@@ -318,10 +313,19 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
             bool up = lo_up;
             if (!hi_up && !lo_up) up = dhi < dlo;
             const int dir = up ? 1 : -1;
-            if (w.axis) w.ci += dir; else w.cj += dir;
-            memo_shift(memo, w.axis, dir);
+            // the centre moves by `dir` along `axis` (Optim.cpp:436-470): cells that scroll in are unknown
+            if (w.axis) {
+                w.ci += dir;
+                w.bi = up ? wrap5(w.bi + 1) : (w.bi == 0 ? 4 : w.bi - 1);
+                w.known = up ? (w.known >> 5) : ((w.known << 5) & 0x1FFFFFFu);
+                w.found0 = 0;
+            } else {
+                w.cj += dir;
+                w.bj = up ? wrap5(w.bj + 1) : (w.bj == 0 ? 4 : w.bj - 1);
+                w.known = up ? ((w.known & ~0x0108421u) >> 1) : ((w.known & ~0x1084210u) << 1);
+                w.found1 = 0;
+            }
             w.c0 = up ? dhi : dlo;                              // the new centre is the neighbour stepped onto
-            if (w.axis) w.found0 = 0; else w.found1 = 0;
         }
     }
     // fill the 4x4 neighbourhood, asking for what is missing in the reference's order (Optim.cpp:353-362)
@@ -348,7 +352,7 @@ __device__ inline void walk_finish(Walk& w, Memo memo, int subpx, double* nb)
         return;
     }
 #pragma unroll
-    for (int g = 0; g < 16; g++) nb[g] = memo[5 * (w.ip + (g >> 2)) + w.jp + (g & 3)];
+    for (int g = 0; g < 16; g++) nb[g] = memo[walk_slot(w, w.ip + (g >> 2), w.jp + (g & 3))];
     double x = 1.0 - w.ip, y = 1.0 - w.jp;                      // Optim.cpp:395-396
     if (subpx == 0) w.out = x;                                  // Optim.cpp:399
     else if (subpx == 1) w.out = spmin_quad(nb, x, y);
