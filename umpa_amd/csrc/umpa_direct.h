@@ -43,6 +43,7 @@ struct RegionArgs {
     double* dbg_d; double* dbg_a; int* dbg_n;
     double* kern; size_t kern_stride;   // DFKernel only: per-pixel 17x17 blur kernels, [tap][pixel]
     int row_base;                       // first region row covered by `kern` (row chunking of DFKernel launches)
+    double* blur; int blur_F;           // DFKernel only: per-pixel blurred reference footprints, [frame][F][F][pixel] (stride = kern_stride)
 };
 
 // descriptor k, read through the CONSTANT address space: the table is written before any kernel runs and k is
@@ -103,6 +104,59 @@ __device__ __forceinline__ double blur_at(const UMPA_GLOBAL double* img, const U
     return MASK ? acc / wsum : acc;
 }
 
+// The kernel-dark-field model blurs the reference with the PIXEL's kernel (Model.cpp:88-117, :997-1151): the blurred
+// values a pixel's evaluations read all lie in one footprint around it -- its window, widened by max_shift - 1 where the
+// reference window moves -- and do not depend on the shift.  The reference (and round 1 here) recomputes the 289-tap
+// blur of every window element at every evaluation, ~18 times per pixel; this fills the footprint once.  Per footprint
+// row and chunk of 8 columns: for each kernel row, 24 image values and 17 kernel values feed 8 x 17 FMAs (0.3 loads per
+// FMA instead of 2), every output summing its taps in blur_at's order (kernel rows outer, columns inner), so the
+// values are those of blur_at bit for bit.
+#define UMPA_BLUR_CHUNK 8
+template <bool MASK>
+__device__ inline void blur_footprint(const ModelDev& m, int i, int j, const UMPA_GLOBAL double* kern, size_t stride,
+                                      UMPA_GLOBAL double* blur, int F, int halo)
+{
+    const int pad = m.padding;
+    for (int k = 0; k < m.Na; k++) {
+        const FrameDesc f = load_frame(m.frames, k);
+        const int li = i - f.pi, lj = j - f.pj;
+        if (li - pad < 0 || li + pad > f.H || lj - pad < 0 || lj + pad > f.W) continue;     // frame does not contribute here
+        UMPA_GLOBAL double* out = blur + (size_t)k * F * F * stride;
+        const UMPA_GLOBAL double* img = gp(f.ref);
+        const UMPA_GLOBAL double* wgt = gp(f.mask);
+        for (int fy = 0; fy < F; fy++) {
+            for (int fx0 = 0; fx0 < F; fx0 += UMPA_BLUR_CHUNK) {
+                double acc[UMPA_BLUR_CHUNK], wacc[UMPA_BLUR_CHUNK];
+#pragma unroll
+                for (int o = 0; o < UMPA_BLUR_CHUNK; o++) { acc[o] = 0.0; wacc[o] = 0.0; }
+                for (int a = -UMPA_BLUR_HALF; a <= UMPA_BLUR_HALF; a++) {
+                    const size_t row = (size_t)(li - halo + fy + a) * f.W;
+                    const int c0 = lj - halo + fx0 - UMPA_BLUR_HALF;
+                    double v[UMPA_BLUR_CHUNK + UMPA_BLUR_SIDE - 1], wv[MASK ? UMPA_BLUR_CHUNK + UMPA_BLUR_SIDE - 1 : 1], kv[UMPA_BLUR_SIDE];
+#pragma unroll
+                    for (int t = 0; t < UMPA_BLUR_CHUNK + UMPA_BLUR_SIDE - 1; t++) {
+                        const int c = min(c0 + t, f.W - 1);                      // past the footprint's last column: unused outputs
+                        v[t] = img[row + c];
+                        if (MASK) wv[t] = wgt[row + c];
+                    }
+#pragma unroll
+                    for (int b = 0; b < UMPA_BLUR_SIDE; b++) kv[b] = kern[(size_t)((a + UMPA_BLUR_HALF) * UMPA_BLUR_SIDE + b) * stride];
+#pragma unroll
+                    for (int o = 0; o < UMPA_BLUR_CHUNK; o++)
+#pragma unroll
+                        for (int b = 0; b < UMPA_BLUR_SIDE; b++) {
+                            if (MASK) { acc[o] += kv[b] * v[o + b] * wv[o + b]; wacc[o] += kv[b] * wv[o + b]; }
+                            else acc[o] += kv[b] * v[o + b];
+                        }
+                }
+#pragma unroll
+                for (int o = 0; o < UMPA_BLUR_CHUNK; o++)
+                    if (fx0 + o < F) out[(size_t)(fy * F + fx0 + o) * stride] = MASK ? acc[o] / wacc[o] : acc[o];
+            }
+        }
+    }
+}
+
 // One cost evaluation at pixel (i,j), shift (si rows, sj cols).  KIND: 0 NoDF, 1 DF, 2 DFKernel
 // (NoDF arithmetic on a reference blurred on the fly, Model.cpp:997-1151).
 // NWC > 0: the window half-width is a compile-time constant (the column loop unrolls, all loads of a window row are
@@ -110,7 +164,8 @@ __device__ __forceinline__ double blur_at(const UMPA_GLOBAL double* img, const U
 template <int KIND, bool MASK, int NWC = 0>
 __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int si, int sj,
                                            double& cost, Fit& fit,
-                                           const UMPA_GLOBAL double* kern = nullptr, size_t kstride = 0)
+                                           const UMPA_GLOBAL double* kern = nullptr, size_t kstride = 0,
+                                           const UMPA_GLOBAL double* blur = nullptr, int blur_F = 0)
 {
     const int ms = m.ms;
     // Model.cpp:372-399 / :654-681 (flags are asymmetric in the reference; kept)
@@ -179,8 +234,12 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
                 }
             }
             for (; b < S; b++) {
-                const double r = KIND == 2 ? blur_at<MASK>(gp(f.ref), gp(f.mask), f.W, ri - f.pi - Nw + a, rj - f.pj - Nw + b, kern, kstride)
-                                           : R[off + b];
+                double r;
+                if (KIND == 2 && blur) {                 // the pixel's blurred footprint (blur_footprint): rows / columns relative to (i, j) - halo
+                    const int halo = (blur_F - 1) >> 1;
+                    r = blur[((size_t)k * blur_F * blur_F + (size_t)(ri - i + halo - Nw + a) * blur_F + (rj - j + halo - Nw + b)) * kstride];
+                } else if (KIND == 2) r = blur_at<MASK>(gp(f.ref), gp(f.mask), f.W, ri - f.pi - Nw + a, rj - f.pj - Nw + b, kern, kstride);
+                else r = R[off + b];
                 term(wrow[b], r, Q[off + b], MASK ? MR[off + b] : 0.0, MASK ? MQ[off + b] : 0.0);
             }
         }
@@ -261,12 +320,17 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
         const UMPA_GLOBAL double* v = gp(A.values) + px * A.v_px;
         build_blur_kernel(kern, A.kern_stride, v[4 * A.v_k], v[5 * A.v_k], v[6 * A.v_k]);
     }
+    UMPA_GLOBAL double* blur = nullptr;
+    if (KIND == 2 && A.blur) {                           // the blurred reference this pixel can ever read, once
+        blur = gpw(A.blur) + ((size_t)(xi - A.row_base) * A.N1 + xj);
+        blur_footprint<MASK>(m, i, j, kern, A.kern_stride, blur, A.blur_F, (A.blur_F - 1) >> 1);
+    }
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
     while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
-        const int st = eval_direct<KIND, MASK, NWC>(m, i, j, w.req_i, w.req_j, c, fit, kern, A.kern_stride);
+        const int st = eval_direct<KIND, MASK, NWC>(m, i, j, w.req_i, w.req_j, c, fit, kern, A.kern_stride, blur, A.blur_F);
         walk_feed(w, memo, st, c, fit, m.call_cap);
     }
     double nb[16];

@@ -267,7 +267,7 @@ hipError_t launch_staged(umpa_hip_model* m, const RegionArgs& A, const StagedGeo
 int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags = 0)
 {
     RegionArgs A = A0;
-    A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
+    A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0;
     // the staged kernel (windows out of LDS) for regions of more than a few pixels whose footprints fit; the plain one
     // (windows through L1) for the kernel-dark-field model, single pixels, large steps, or on request
     static const bool no_staged = getenv("UMPA_HIP_NO_STAGED") != nullptr;
@@ -285,10 +285,15 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
         return 0;
     }
     if (m->kind == UMPA_HIP_KIND_DFKERNEL) {
-        // every pixel carries its own 17x17 blur kernel (Model.cpp:88-117): 289 doubles of scratch per pixel,
-        // so the region is matched in row chunks whose scratch stays below 1 GiB
-        const size_t per_row = (size_t)UMPA_BLUR_TAPS * A.N1 * sizeof(double);
-        int rows_chunk = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_row);
+        // every pixel carries its own 17x17 blur kernel (Model.cpp:88-117: 289 doubles) and, unless UMPA_HIP_DFK_NO_REUSE
+        // is set, the reference blurred with it over the footprint its evaluations read (blur_footprint: Na * F * F
+        // doubles): the region is matched in row chunks whose scratch stays below 2 GiB
+        static const bool no_reuse = getenv("UMPA_HIP_DFK_NO_REUSE") != nullptr;
+        const int halo = m->Nw + (m->ref_mode ? 0 : std::max(m->ms - 1, 0));    // the reference window moves in 'sam' mode only
+        const int F = 2 * halo + 1;
+        const size_t per_px = (size_t)UMPA_BLUR_TAPS + (no_reuse ? 0 : (size_t)m->Na * F * F);
+        const size_t per_row = per_px * A.N1 * sizeof(double);
+        int rows_chunk = (int)std::max<size_t>(1, ((size_t)2 << 30) / per_row);
         rows_chunk = std::min(rows_chunk, A.N0);
         if (m->b_kern.reserve(per_row * rows_chunk)) return fail(UMPA_HIP_E_NOMEM, "blur-kernel scratch");
         for (int row0 = 0; row0 < A0.N0; row0 += rows_chunk) {
@@ -304,6 +309,8 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
             C.dbg_a = A0.dbg_a ? A0.dbg_a + 16 * px0 : nullptr;
             C.dbg_n = A0.dbg_n ? A0.dbg_n + px0 : nullptr;
             C.kern = (double*)m->b_kern.p; C.kern_stride = (size_t)C.N0 * C.N1; C.row_base = 0;
+            C.blur = no_reuse ? nullptr : C.kern + (size_t)UMPA_BLUR_TAPS * C.kern_stride;
+            C.blur_F = F;
             if (m->has_mask) launch_direct<2, true>(m, C, s); else launch_direct<2, false>(m, C, s);
             HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
         }
@@ -713,7 +720,7 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
     RegionArgs A;
     A.org0 = m->padding + start0; A.step0 = step0; A.N0 = N0;       // model.pyx:482-483
     A.org1 = m->padding + start1; A.step1 = step1; A.N1 = N1;
-    A.nparam = nparam; A.thr = cover_threshold; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
+    A.nparam = nparam; A.thr = cover_threshold; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0;
     const bool planar = (flags & UMPA_HIP_F_PLANAR) != 0;
     A.v_px = planar ? 1 : (size_t)nparam; A.v_k = planar ? n : 1;
 
@@ -823,7 +830,7 @@ int umpa_hip_min(umpa_hip_model* m, int i, int j, double* values, double* uv, do
     RegionArgs A;
     A.org0 = i; A.step0 = 1; A.N0 = 1; A.org1 = j; A.step1 = 1; A.N1 = 1;      // Model::min takes absolute coordinates
     A.values = d; A.nparam = np; A.v_px = np; A.v_k = 1; A.uv = d + 8; A.err = (int*)(d + 10); A.cover = nullptr; A.thr = 0.0;
-    A.dbg_n = (int*)(d + 11); A.dbg_d = d + 12; A.dbg_a = d + 37; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0;
+    A.dbg_n = (int*)(d + 11); A.dbg_d = d + 12; A.dbg_a = d + 37; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0;
     if (int rc = run_direct(m, A, s)) return rc;
     HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
     HIP_TRY(hipStreamSynchronize(s), UMPA_HIP_E_DEVICE);
