@@ -12,8 +12,8 @@
 //     only, t3, t2, t6 and the per-frame windowed reference mean on the reference-window
 //     position only, and  t4(p,u) = sum_k mean_k(x_ref) W[s_k](x_sam)  is a K-term dot product.
 //
-//   prep_maps   : per frame separable window sums -> maps SamSq (t1), RefSq (t3), RefM2 (t2),
-//                 RefM6 (t6) and per-frame WS_k = W[s_k], MR_k = W[r_k]/sum(w).       HBM-bound.
+//   prep_maps   : per frame separable window sums -> maps SamSq (t1), RefSq (t3) and per-frame
+//                 WS_k = W[s_k], MR_k = W[r_k]/sum(w) (t2 and t6 are sums over k of MR_k^2).  HBM-bound.
 //   corr_volume : the exhaustive table t5[u][p] for all (2 max_shift - 1)^2 integer shifts of a
 //                 row chunk: product planes accumulated over frames in registers, then the two
 //                 1-D filters through LDS.  K + 2(2Nw+1) FMAs per (p,u) before halo overhead.
@@ -36,8 +36,6 @@ namespace umpa {
 struct Maps {                        // prep_maps outputs, each a full H x W plane (borders unused)
     double* SamSq;                   // sum_k W[s_k^2]                      -> t1
     double* RefSq;                   // sum_k W[r_k^2]                      -> t3
-    double* RefM2;                   // sum_k mean_k^2                      -> t2   (DF)
-    double* RefM6;                   // sum_k mean_k W[r_k]                 -> t6   (DF)
     double* WS;                      // [K] planes W[s_k]                           (DF)
     double* MR;                      // [K] planes mean_k = W[r_k]/sum(w)           (DF)
     int H, W;
@@ -61,7 +59,7 @@ template <int KIND, int NW>
 __global__ void __launch_bounds__(256)
 prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
 {
-    // sides: bit 0 = the sample-side maps (SamSq, WS_k), bit 1 = the reference-side maps (RefSq, RefM2, RefM6, MR_k).
+    // sides: bit 0 = the sample-side maps (SamSq, WS_k), bit 1 = the reference-side maps (RefSq, MR_k).
     // A model whose reference stack has not changed since the last match only recomputes the sample side.
     const bool do_ref = (sides & 2) != 0;
     using C = PrepCfg<NW>;
@@ -80,9 +78,9 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
     // V-stage ownership: item = (sq, rb, c), c fastest: 2 planes x 4 row blocks x 32 columns = 256 items, one per
     // thread and stack (wave-uniform sq).  acc[st]: sums over the frames for stack st (0 sample, 1 reference).
     const int vc = tid & 31, vrb = (tid >> 5) & 3, vsq = tid >> 7;
-    double acc[2][C::CB], acc2[C::CB];
+    double acc[2][C::CB];
 #pragma unroll
-    for (int o = 0; o < C::CB; o++) { acc[0][o] = acc[1][o] = 0.0; acc2[o] = 0.0; }
+    for (int o = 0; o < C::CB; o++) acc[0][o] = acc[1][o] = 0.0;
 
     // staging slots of this thread: compile-time count, so the frame k+1 can wait in registers while frame k is filtered
     constexpr int NS = (C::Q * C::Q + C::NT - 1) / C::NT;
@@ -148,12 +146,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
                     const bool inside = gr < M.H - NW && gc < M.W - NW;
                     if (vsq == 1) acc[st][o] += out[o];               // t1 / t3
                     else if (st == 0) { if (inside) gpw(M.WS)[k * plane + (size_t)gr * M.W + gc] = out[o]; }
-                    else {
-                        const double mean = out[o] / m.win_sum;       // Model.cpp:739
-                        if (inside) gpw(M.MR)[k * plane + (size_t)gr * M.W + gc] = mean;
-                        acc[1][o] += mean * mean;                     // t2, Model.cpp:770
-                        acc2[o] += mean * out[o];                     // t6, Model.cpp:772
-                    }
+                    else if (inside) gpw(M.MR)[k * plane + (size_t)gr * M.W + gc] = out[o] / m.win_sum;   // Model.cpp:739
                 }
             }
         }
@@ -167,7 +160,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
         if (vsq == 1) {
             gpw(M.SamSq)[g] = acc[0][o];
             if (do_ref) gpw(M.RefSq)[g] = acc[1][o];
-        } else if (KIND == 1 && do_ref) { gpw(M.RefM2)[g] = acc[1][o]; gpw(M.RefM6)[g] = acc2[o]; }
+        }
     }
 }
 
@@ -195,12 +188,20 @@ __device__ __forceinline__ double ld_off(const UMPA_GLOBAL double* base, unsigne
     return *reinterpret_cast<const UMPA_GLOBAL double*>(reinterpret_cast<const UMPA_GLOBAL char*>(base) + byte_off);
 }
 
+// What an evaluation needs of the pixel itself, loaded or summed once before the walk: in 'sam' mode the sample window
+// does not move (t1), in 'ref' mode the reference window does not (t3, t2, t6).
+struct PixConst { double t1, t3, t2, t6; };
+
+// t2 = sum_k mean_k^2 and t6 = sum_k mean_k W[r_k] (Model.cpp:770-772) from the per-frame means, which an evaluation
+// has in registers anyway: W[r_k] = mean_k * sum(w) by the definition of the mean (Model.cpp:739), so t6 = sum(w) t2.
+// (Two map planes and two cache-line streams per evaluation less than reading them back.)
+
 // NA > 0: the number of frames is a compile-time constant (<= UMPA_KTEMPL) and every map plane is addressable
 // with 32-bit byte offsets: straight-line code, no per-frame tests.  NA == 0: any frame count.
 template <int KIND, int NA>
 __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, const ReplayArgs& R, int ref_mode,
                                            int i, int j, size_t tpx, int si, int sj,
-                                           const double* fixed, double& cost, Fit& fit)
+                                           const double* fixed, const PixConst& pc, double& cost, Fit& fit)
 {
     const int ms = m.ms;
     if (si <= -ms || si >= ms) return UMPA_ST_BOUND;
@@ -214,41 +215,35 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
     const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
     const double rwt = 1.0 / (double)m.Na;                          // wave-uniform: scalar
-    double t1, t3;
-    if (NA > 0) {
-        t1 = ld_off(gp(M.SamSq), (unsigned)xs * 8u);
-        t3 = ld_off(gp(M.RefSq), (unsigned)xr * 8u);
-    } else {
-        t1 = gp(M.SamSq)[xs];
-        t3 = gp(M.RefSq)[xr];
-    }
+    double t1 = pc.t1, t3 = pc.t3;
+    if (ref_mode) t1 = NA > 0 ? ld_off(gp(M.SamSq), (unsigned)xs * 8u) : gp(M.SamSq)[xs];
+    else t3 = NA > 0 ? ld_off(gp(M.RefSq), (unsigned)xr * 8u) : gp(M.RefSq)[xr];
     if (KIND == 1) {
-        double t2, t6, t4 = 0.0;
+        double t2 = 0.0, t4 = 0.0;
         const size_t plane = (size_t)M.H * M.W;
         if (NA > 0) {
-            const unsigned br = (unsigned)xr * 8u, bm = (unsigned)(ref_mode ? xs : xr) * 8u;
-            t2 = ld_off(gp(M.RefM2), br);
-            t6 = ld_off(gp(M.RefM6), br);
+            const unsigned bm = (unsigned)(ref_mode ? xs : xr) * 8u;
             const UMPA_GLOBAL double* __restrict__ mov = gp(ref_mode ? M.WS : M.MR);
             double mv[NA > 0 ? NA : 1];
 #pragma unroll
             for (int k = 0; k < NA; k++) mv[k] = ld_off(mov + k * plane, bm);          // all loads in flight together
 #pragma unroll
-            for (int k = 0; k < NA; k++) t4 += mv[k] * fixed[k];
+            for (int k = 0; k < NA; k++) { t4 = fma(mv[k], fixed[k], t4); t2 = fma(mv[k], mv[k], t2); }
         } else {
-            t2 = gp(M.RefM2)[xr];
-            t6 = gp(M.RefM6)[xr];
             const UMPA_GLOBAL double* __restrict__ mov = gp(ref_mode ? M.WS : M.MR) + (ref_mode ? xs : xr);
             double mv[UMPA_KFIX];
 #pragma unroll
             for (int k = 0; k < UMPA_KFIX; k++) mv[k] = k < m.Na ? mov[k * plane] : 0.0;
 #pragma unroll
-            for (int k = 0; k < UMPA_KFIX; k++) if (k < m.Na) t4 += mv[k] * fixed[k];
+            for (int k = 0; k < UMPA_KFIX; k++) if (k < m.Na) { t4 = fma(mv[k], fixed[k], t4); t2 = fma(mv[k], mv[k], t2); }
             if (m.Na > UMPA_KFIX) {
                 const UMPA_GLOBAL double* __restrict__ fx = gp(ref_mode ? M.MR : M.WS) + (ref_mode ? xr : xs);
-                for (int k = UMPA_KFIX; k < m.Na; k++) t4 += mov[k * plane] * fx[k * plane];
+                for (int k = UMPA_KFIX; k < m.Na; k++) { const double a = mov[k * plane]; t4 = fma(a, fx[k * plane], t4); t2 = fma(a, a, t2); }
             }
         }
+        double t6;
+        if (ref_mode) { t2 = pc.t2; t6 = pc.t6; }                   // the moving maps were the sample's: the means are the pixel's own
+        else t6 = m.win_sum * t2;
         // Model.cpp:849-858 with one reciprocal instead of the reference's three divisions by the same
         // determinant and the division by wt (1-ulp level differences; the bar is 1e-5).  The dark-field
         // value v = K/T is only needed for the pixel's final answer: `fit.v` carries K, replay_walk divides once.
@@ -293,6 +288,19 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
 #pragma unroll
         for (int k = 0; k < NFIX; k++) fixed[k] = (NA > 0 || k < m.Na) ? fx[k * plane] : 0.0;
     }
+    PixConst pc = {0.0, 0.0, 0.0, 0.0};
+    {
+        const size_t x0 = (size_t)i * M.W + j;
+        if (m.ref_mode) {
+            pc.t3 = gp(M.RefSq)[x0];
+            if (KIND == 1) {                                        // the means at the pixel: `fixed` for k < NFIX, the planes beyond
+#pragma unroll
+                for (int k = 0; k < NFIX; k++) if (NA > 0 || k < m.Na) pc.t2 = fma(fixed[k], fixed[k], pc.t2);
+                for (int k = NFIX; k < m.Na; k++) { const double a = gp(M.MR)[(size_t)k * M.H * M.W + x0]; pc.t2 = fma(a, a, pc.t2); }
+                pc.t6 = m.win_sum * pc.t2;
+            }
+        } else pc.t1 = gp(M.SamSq)[x0];
+    }
     const LdsMemo<UMPA_REPLAY_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
@@ -301,7 +309,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
         Fit fit = w.live;
         for (int n = 0; n < 18; n++) {
             double c = 0.0;
-            eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, (n % 5) - 2, (n / 5) - 2, fixed, c, fit);
+            eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, (n % 5) - 2, (n / 5) - 2, fixed, pc, c, fit);
             csum += c;
         }
         w.out = csum; w.live = fit; w.phase = PH_DONE; w.status = 1;
@@ -309,7 +317,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
     while (w.phase < PH_FIT) {
         double c = 0.0;
         Fit fit = w.live;
-        const int st = eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, c, fit);
+        const int st = eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, pc, c, fit);
         walk_feed(w, memo, st, c, fit, m.call_cap);
     }
     double nb[16];
@@ -525,7 +533,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
 {
     const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1;
     const size_t plane = (size_t)H * W;
-    const size_t nmaps = kind == 1 ? 4 + 2 * (size_t)K : 2;
+    const size_t nmaps = kind == 1 ? 2 + 2 * (size_t)K : 2;
     if (st.maps_cap < nmaps * plane) {
         if (st.maps) (void)hipFree(st.maps);
         st.maps = nullptr; st.maps_cap = 0;
@@ -537,10 +545,8 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     Maps M;
     M.H = H; M.W = W;
     M.SamSq = st.maps; M.RefSq = st.maps + plane;
-    M.RefM2 = kind == 1 ? st.maps + 2 * plane : nullptr;
-    M.RefM6 = kind == 1 ? st.maps + 3 * plane : nullptr;
-    M.WS = kind == 1 ? st.maps + 4 * plane : nullptr;
-    M.MR = kind == 1 ? st.maps + (4 + (size_t)K) * plane : nullptr;
+    M.WS = kind == 1 ? st.maps + 2 * plane : nullptr;
+    M.MR = kind == 1 ? st.maps + (2 + (size_t)K) * plane : nullptr;
 
     // The table lives on the dense (unit-step) grid under the region: with step > 1 every step-th entry is used
     // (tiled_applicable only sends small steps here).  Rows per chunk: the shift table of one chunk stays within
