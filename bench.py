@@ -16,8 +16,9 @@ N > 1   (launched by torch.distributed.run, one rank per GPU, RCCL) BASELINE con
         A step is what the path does with such an image:
           1. halo exchange: every rank tops its block up with the boundary rows of its neighbours
              (sharding.exchange_halos: one ncclSend/ncclRecv group over xGMI, device tensors);
-          2. match of the rank's output-row slab (1021/1022 rows at N = 8);
-          3. gather of the result slabs on rank 0 (sharding.gather_slabs, RCCL).
+          2. match of the rank's output-row slab (1021/1022 rows at N = 8), in four row pieces;
+          3. gather of the result slabs on rank 0: the rows of a piece start travelling (sharding.send_rows_to, one
+             RCCL send/recv group per piece) as soon as its kernels are enqueued, overlapping the next piece.
         Per-GPU work is the same for every N (weak scaling); `value` counts the output pixels of the whole image.
 
 Rank 0 prints ONE JSON line (see the driver contract), including
@@ -262,17 +263,42 @@ def sharded(args, world, rank, local, dev, backend):
     stream = torch.cuda.current_stream().cuda_stream
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
+    # The slab is matched in four row pieces; as soon as the kernels of a piece are enqueued its rows start travelling
+    # to rank 0 (one RCCL send/recv group per piece, behind the piece's kernels in stream order), so that the gather
+    # overlaps the matching of the next piece instead of following the whole match.  UMPA_BENCH_GATHER=after: one gather
+    # of the padded slabs after the match (sharding.gather_slabs), for comparison.
+    overlap = os.environ.get("UMPA_BENCH_GATHER", "pieces") != "after"
+    piece_rows = ((-(-biggest // 4)) + 31) // 32 * 32                # the same on every rank
+    pending = []
+
+    def on_rows(lo, hi, _user):
+        if hi >= N0:
+            hi = biggest                                              # last piece: slabs differ by a row
+        pending.extend(sharding.send_rows_to([values, err], [whole_v, whole_e], n_out, lo, hi, dst=0))
+
+    cb = _lib.ROWS_FN(on_rows)
+
     def step(marks=None, with_ncalls=False):
+        nonlocal overlap
         if marks: marks[0].record()
         sharding.exchange_halos([st_s, st_r])
         if marks: marks[1].record()
+        if overlap:
+            lib.check(lib.set_rows_callback(h, ctypes.cast(cb, ctypes.c_void_p), None, piece_rows), "set_rows_callback")
         rc = lib.match_region(h, 0, 1, N0, 0, 1, N1, values.data_ptr(), nparam, None, err.data_ptr(),
                               None, 0.0, None, None, ncalls.data_ptr() if with_ncalls else None, flags,
                               ctypes.c_void_p(stream))
+        if overlap:
+            lib.set_rows_callback(h, None, None, 0)
         lib.check(rc, "match_region")
         if marks: marks[2].record()
-        sharding.gather_slabs(values, n_out, dst=0, out=whole_v)
-        sharding.gather_slabs(err, n_out, dst=0, out=whole_e)
+        if overlap:
+            for w in pending:
+                w.wait()
+            del pending[:]
+        else:
+            sharding.gather_slabs(values, n_out, dst=0, out=whole_v)
+            sharding.gather_slabs(err, n_out, dst=0, out=whole_e)
         if marks: marks[3].record()
 
     def fence():
@@ -280,7 +306,19 @@ def sharded(args, world, rank, local, dev, backend):
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # self-check of the piecewise gather on the first (untimed) step: every row of the whole maps must have arrived on
+    # rank 0; if not, every rank falls back to the gather after the match
+    if rank == 0:
+        whole_e.fill_(-7)
+    step()
+    fence()
+    good = torch.tensor([1 if (rank != 0 or bool((whole_e != -7).all().item())) else 0], dtype=torch.int32, device=coll)
+    dist.all_reduce(good, op=dist.ReduceOp.MIN)
+    if overlap and int(good.item()) == 0:
+        overlap = False
+        if rank == 0:
+            print("bench.py: the piecewise gather left rows unwritten; using the gather after the match", file=sys.stderr)
+    for _ in range(max(args.warmup - 1, 0)):
         step()
     fence()
     lib.timing_enable(h, 1)
@@ -321,6 +359,8 @@ def sharded(args, world, rank, local, dev, backend):
                        "rccl_world_size": world,
                        "halo_ms": round(float(tmax[1]), 4), "match_ms": round(float(tmax[2]), 4),
                        "gather_ms": round(float(tmax[3]), 4),
+                       "gather_mode": "row pieces of %d rows sent while the next piece is matched; gather_ms is what is left "
+                                      "after the match" % piece_rows if overlap else "after the match",
                        "halo_bytes_received_per_rank": st_s.halo_bytes() + st_r.halo_bytes(),
                        "gather_bytes_to_rank0": int((biggest * N1 * (nparam * 8 + 4)) * (world - 1)),
                        "Ncalls_mean_rank0": round(float(nc.mean()), 3),

@@ -101,6 +101,15 @@ int umpa_hip_update_frames(umpa_hip_model *m, double *const *sam, double *const 
  * umpa_hip_match_region with UMPA_HIP_F_USE_STAGED, in stream order.  Only for models that own their frames. */
 int umpa_hip_stage_sample(umpa_hip_model *m, const void *const *raw, int raw_dtype,
                           const double *const *dark, const double *const *flat);
+/* Device-resident outputs (UMPA_HIP_F_DEVICE_IO) in row pieces: the region is matched in row chunks of `piece_rows`
+ * rows (rounded up to a multiple of 32; the same boundaries on every rank of a sharded match whatever its slab size), and
+ * fn(lo, hi, user) is called on the calling thread as soon as the kernels that complete output rows [lo, hi) are enqueued
+ * on the match's stream -- the caller can queue work behind them there (a send of those rows to another GPU, a
+ * download) that overlaps the matching of the next piece.  fn = NULL switches it off.  (bench.py --gpus N: the gather
+ * of the result slabs on rank 0 travels piece by piece while the slab is still being matched.) */
+typedef void (*umpa_hip_rows_fn)(int row_lo, int row_hi, void *user);
+int umpa_hip_set_rows_callback(umpa_hip_model *m, umpa_hip_rows_fn fn, void *user, int piece_rows);
+
 /* wait for an UMPA_HIP_F_ASYNC match of this model (kernels and downloads); returns its status */
 int umpa_hip_wait(umpa_hip_model *m);
 /* page-lock / release memory the caller owns (a shared-memory ring that feeds umpa_hip_stage_sample) */

@@ -234,11 +234,44 @@ def _gpu_sharded_worker(rank, world, port, tmp, backend):
             got = sharding.gather_slabs(pad, n_out, dst=0)
             if rank == 0:
                 whole[k] = got.cpu().numpy()
+        # the form bench.py --gpus N times: device-resident outputs, the slab matched in row pieces, the rows of a piece
+        # sent to rank 0 from the library's callback while the next piece is matched
+        import ctypes
+        from umpa_amd import _lib
+        N0 = r1 - r0
+        values = torch.zeros((biggest, N1, 5), dtype=torch.float64, device=dev)
+        err = torch.zeros((biggest, N1), dtype=torch.int32, device=dev)
+        whole_v = torch.full((n_out, N1, 5), float("nan"), dtype=torch.float64, device=dev) if rank == 0 else None
+        whole_e = torch.full((n_out, N1), -7, dtype=torch.int32, device=dev) if rank == 0 else None
+        pending, seen = [], []
+
+        def on_rows(lo, hi, _user):
+            seen.append((lo, hi))
+            if hi >= N0:
+                hi = biggest
+            pending.extend(sharding.send_rows_to([values, err], [whole_v, whole_e], n_out, lo, hi, dst=0))
+
+        cb = _lib.ROWS_FN(on_rows)
+        lib, h = m._lib, m._handle
+        lib.check(lib.set_rows_callback(h, ctypes.cast(cb, ctypes.c_void_p), None, 32), "set_rows_callback")
+        rc = lib.match_region(h, 0, 1, N0, 0, 1, N1, values.data_ptr(), 5, None, err.data_ptr(), None, 0.0, None, None, None,
+                              _lib.F_DEVICE_IO, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        lib.set_rows_callback(h, None, None, 0)
+        lib.check(rc, "match_region")
+        for w in pending:
+            w.wait()
+        torch.cuda.synchronize()
+        assert len(seen) == -(-N0 // 32) and seen[0][0] == 0 and seen[-1][1] == N0
+
         if rank == 0:
             full = model.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms, device=local).match(quiet=True)
             for k in whole:
                 np.testing.assert_array_equal(whole[k], full[k], err_msg=k)
             assert full["err"].mean() > 0.5
+            wv, we = whole_v.cpu().numpy(), whole_e.cpu().numpy()
+            np.testing.assert_array_equal(we, full["err"])
+            for n, k in enumerate(("f", "T", "dx", "dy", "df")):
+                np.testing.assert_array_equal(wv[:, :, n], full[k], err_msg="pieces " + k)
             open(os.path.join(tmp, "sharded_ok_" + backend), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -26,7 +26,7 @@ _dpp = C.POINTER(_dp)
 HIP_SYMBOLS = [
     "device_count", "last_error", "version", "create", "destroy", "set_window", "set_subpx",
     "set_reference_shift", "coverage", "coverage_region", "cost", "min", "match_region",
-    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path", "host_alloc", "host_free", "host_trim", "stage_sample", "wait", "host_register", "host_unregister",
+    "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path", "host_alloc", "host_free", "host_trim", "stage_sample", "wait", "set_rows_callback", "host_register", "host_unregister",
     "update_frames", "correct_bad_pixels",
 ]
 
@@ -81,6 +81,7 @@ class Native:
             f("host_trim", None, [])
             f("stage_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p])
             f("wait", C.c_int, [C.c_void_p])
+            f("set_rows_callback", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int])
             f("host_register", C.c_int, [C.c_void_p, C.c_size_t])
             f("host_unregister", C.c_int, [C.c_void_p])
             f("last_path", C.c_int, [C.c_void_p])
@@ -135,6 +136,9 @@ def hip():
         _pin_hip_runtime()
         _hip = Native(HIP_LIB_PATH, "umpa_hip_", True)
     return _hip
+
+
+ROWS_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_void_p)       # umpa_hip_rows_fn
 
 
 def pinned_empty(shape, dtype, zero=False):

@@ -86,6 +86,9 @@ struct umpa_hip_model {
     bool read_once[2] = {false, false};
     bool staged = false;
     std::vector<hipEvent_t> pending_events;        // of an UMPA_HIP_F_ASYNC match, recycled by umpa_hip_wait
+    umpa_hip_rows_fn rows_cb = nullptr;            // umpa_hip_set_rows_callback: told after the kernels of a row piece are enqueued
+    void* rows_user = nullptr;
+    int rows_piece_rows = 0;
     FrameDesc* h_desc = nullptr;                   // pinned host copy of the descriptor table (source of the stream-ordered update)
     DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small, b_kern;
     TiledState tiled;                              // scratch of the tiled fast path
@@ -345,7 +348,7 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
 }
 
 int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
-              int pieces = 1, const std::function<void(int, int)>& on_rows = nullptr)
+              int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
 {
     const bool can_tile = tiled_applicable(m, A);
     if ((flags & UMPA_HIP_F_FORCE_TILED) && !can_tile)
@@ -354,7 +357,7 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
         TiledTimers tt;
         tt.get = [m]() { return get_event(m); };
         int rc = tiled_match(m->tiled, m->dev(), m->kind, m->dims[0], m->dims[1], A, s,
-                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, pieces, on_rows);
+                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
         if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
         if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
         for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; m->launches.push_back(tl); }
@@ -563,6 +566,13 @@ int umpa_hip_stage_sample(umpa_hip_model* m, const void* const* raw, int raw_dty
     return 0;
 }
 
+int umpa_hip_set_rows_callback(umpa_hip_model* m, umpa_hip_rows_fn fn, void* user, int piece_rows)
+{
+    if (!m) return fail(UMPA_HIP_E_ARG, "null model");
+    m->rows_cb = fn; m->rows_user = user; m->rows_piece_rows = piece_rows > 0 ? piece_rows : 0;
+    return 0;
+}
+
 int umpa_hip_wait(umpa_hip_model* m)
 {
     if (!m) return fail(UMPA_HIP_E_ARG, "null model");
@@ -728,7 +738,11 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
         A.values = values; A.uv = uv; A.err = err; A.cover = covermap;
         A.dbg_d = dbg_d; A.dbg_a = dbg_a; A.dbg_n = dbg_ncalls;
         if (int rc = adopt_staged(m, flags, (hipStream_t)stream)) return rc;
-        if (int rc = run_match(m, A, flags, (hipStream_t)stream)) return rc;
+        if (m->rows_cb) {
+            umpa_hip_rows_fn cb = m->rows_cb;
+            void* user = m->rows_user;
+            if (int rc = run_match(m, A, flags, (hipStream_t)stream, m->rows_piece_rows, [cb, user](int lo, int hi) { cb(lo, hi, user); })) return rc;
+        } else if (int rc = run_match(m, A, flags, (hipStream_t)stream)) return rc;
         mark_matched(m, (hipStream_t)stream);
         return UMPA_HIP_ST_OK;
     }
@@ -781,7 +795,9 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
         piece_list.push_back(p);
     };
     const int pieces = n >= ((size_t)1 << 21) ? 8 : n >= ((size_t)1 << 19) ? 4 : 1;
-    if (int rc = run_match(m, A, flags, s, pieces, on_rows)) return rc;
+    const int N0d = step0 * (N0 - 1) + 1;
+    const int piece_rows = pieces > 1 ? std::max(4 * UMPA_TILE, (N0d + pieces - 1) / pieces) : 0;
+    if (int rc = run_match(m, A, flags, s, piece_rows, on_rows)) return rc;
     mark_matched(m, s);
 
     hipStream_t cs = m->copy_stream;

@@ -524,12 +524,12 @@ inline size_t tiled_table_budget()
 
 // One match of a region on the tiled path.  Returns 0, -3 (allocation) or a positive hipError_t.
 // `reuse_ref_maps`: the caller vouches that the reference frames are those of the previous call (it owns them).
-// `pieces` > 1: split the region into about that many row chunks even where the table budget would allow one (the
-// host-array entry point downloads the rows of chunk c while chunk c+1 is being matched); `on_rows(xi_lo, xi_hi)`
-// is called after the kernels of a chunk have been enqueued.
+// `piece_rows` > 0: row chunks of at most that many dense rows (a multiple of 32) even where the table budget would
+// allow more (the host-array entry point downloads the rows of chunk c while chunk c+1 is being matched, the multi-GPU
+// leg sends them to rank 0); `on_rows(xi_lo, xi_hi)` is called after the kernels of a chunk have been enqueued.
 inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const RegionArgs& A,
                        hipStream_t s, TiledTimers* tt, bool reuse_ref_maps,
-                       int pieces = 1, const std::function<void(int, int)>& on_rows = nullptr)
+                       int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
 {
     const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1;
     const size_t plane = (size_t)H * W;
@@ -556,9 +556,9 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
     if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
     if (rows_chunk > N0d) rows_chunk = ((long)N0d + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
-    if (pieces > 1) {
-        const long want = (((long)N0d + pieces - 1) / pieces + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
-        if (want < rows_chunk) rows_chunk = std::max<long>(want, 4 * UMPA_TILE);
+    if (piece_rows > 0) {
+        const long want = ((long)piece_rows + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+        if (want < rows_chunk) rows_chunk = want;
     }
     {   // eval_lookup multiplies the slot number by a 32-bit slot stride (rows_chunk * N1d)
         const long cap = (long)(0xffffffffull / (size_t)N1d) / UMPA_TILE * UMPA_TILE;

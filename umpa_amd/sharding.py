@@ -22,7 +22,7 @@ Two input situations are covered:
 import numpy as np
 
 __all__ = ["slab_bounds", "input_rows", "match_rows", "exchange_halo", "gather_rows",
-           "RowShardedStack", "exchange_halos", "gather_slabs"]
+           "RowShardedStack", "exchange_halos", "gather_slabs", "send_rows_to", "slab_piece_bounds"]
 
 
 def slab_bounds(n_rows, world, rank):
@@ -229,3 +229,55 @@ def gather_slabs(local, n_rows, dst=0, group=None, out=None):
     for g, (a, b) in enumerate(sizes):
         out[a:b].copy_(bufs[g][: b - a])
     return out
+
+
+def send_rows_to(tensors, wholes, n_rows, lo, hi, dst=0, group=None):
+    """Rows [lo, hi) of every rank's slab travel to ``dst`` NOW (asynchronously): ``tensors`` are this rank's slab
+    tensors (``[slab rows (or more), ...]``), ``wholes`` the matching ``[n_rows, ...]`` tensors on ``dst`` (ignored
+    elsewhere).  One send/recv group per call with exact sizes (slabs may differ by a row); ``dst`` places its own rows
+    with a device copy.  Returns the work handles to wait for.  Called once per finished row piece
+    (``umpa_hip_set_rows_callback``), the transfers overlap the matching of the next piece: every rank must call it with
+    the same sequence of (lo, hi)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [slab_bounds(n_rows, world, g) for g in range(world)]
+    via_host = dist.get_backend(group) != "nccl"
+    ops, landing = [], []
+    if rank == dst:
+        for g, (a, b) in enumerate(sizes):
+            l, h = min(lo, b - a), min(hi, b - a)
+            if h <= l:
+                continue
+            for t, whole in zip(tensors, wholes):
+                if g == rank:
+                    whole[a + l: a + h].copy_(t[l:h], non_blocking=True)
+                elif via_host:
+                    import torch
+                    buf = torch.empty(whole[a + l: a + h].shape, dtype=whole.dtype, device="cpu")
+                    ops.append(dist.P2POp(dist.irecv, buf, g, group))
+                    landing.append((whole[a + l: a + h], buf))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, whole[a + l: a + h], g, group))
+    else:
+        a, b = sizes[rank]
+        l, h = min(lo, b - a), min(hi, b - a)
+        if h > l:
+            for t in tensors:
+                ops.append(dist.P2POp(dist.isend, t[l:h].cpu() if via_host else t[l:h], dst, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if via_host:
+        for w in works:
+            w.wait()
+        for view, buf in landing:
+            view.copy_(buf)
+        return []
+    return works
+
+
+def slab_piece_bounds(n_rows, world, pieces):
+    """The (lo, hi) sequence ``send_rows_to`` must see on every rank when the pieces are announced by a callback whose
+    boundaries depend on the rank's slab size: not used by bench.py (the library announces the same boundaries for
+    slabs that differ by one row only in the last piece), kept for hosts that cut the pieces themselves."""
+    biggest = max(b - a for a, b in (slab_bounds(n_rows, world, g) for g in range(world)))
+    step = -(-biggest // pieces)
+    return [(r, min(r + step, biggest)) for r in range(0, biggest, step)]
