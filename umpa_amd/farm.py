@@ -14,7 +14,7 @@ projections from a queue, picks the nearest reference (``:133``), flat-corrects 
     host buffers, three HIP streams); the reference stack is switched only when the nearest reference changes.
   * ``ProjectionFarm`` runs one ``StreamingMatcher`` per GPU in worker processes.  Projections and result maps travel
     through shared-memory slots that the workers page-lock once, so nothing is pickled and the PCIe transfers run at
-    link rate; an optional writer thread per worker saves ``.npz`` files straight from the result slot.
+    link rate; ``save_pattern`` also writes every result as an ``.npz`` file (``umpa_multi.py:185``).
 
     farm = ProjectionFarm(refs, window_size=5, max_shift=5, devices=[0, 1, 2, 3], flats=flats, dark=dark, ref_nums=ref_nums)
     for pid, res in farm.map((pid, raw_stack) for ...):      # res: dict of arrays (copied out of the result slot)
@@ -26,7 +26,6 @@ The loading / unwarping steps of the reference script are the caller's business 
 import multiprocessing as mp
 import os
 import queue as _queue
-import threading
 import time
 
 import numpy as np
@@ -142,11 +141,14 @@ class _Slots:
         return np.frombuffer(self.shm.buf, dtype=dtype, count=int(np.prod(shape)), offset=start).reshape(shape), offset + ((n + 63) & ~63)
 
     def close(self):
+        if self.owner:                                              # the name goes first: views of the mapping may still be alive
+            try:
+                self.shm.unlink()
+            except Exception:
+                pass
         try:
             self.shm.close()
-            if self.owner:
-                self.shm.unlink()
-        except Exception:
+        except Exception:                                           # BufferError while numpy views exist: the mapping dies with them
             pass
 
 
