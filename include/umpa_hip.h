@@ -187,7 +187,8 @@ int umpa_hip_timing_read(umpa_hip_model *m, int index, const char **name, double
 /* fp64 fused multiply-adds executed by the collected launches of kernel `index` (counted on the host from the launch
  * geometry; filled in for corr_volume, 0 for kernels that do not report it): the numerator of roofline.fp64_fma */
 int umpa_hip_timing_fma(umpa_hip_model *m, int index, double *fma);
-/* which path the last match_region took: 0 none, 1 direct (plain), 2 tiled, 3 direct (staged: windows out of LDS) */
+/* which path the last match_region took: 0 none, 1 direct (plain), 2 tiled, 3 direct (staged: windows out of LDS),
+ * 4 sample stepping: tiled on the rectangle every frame contributes to + general kernels on the border strips */
 int umpa_hip_last_path(umpa_hip_model *m);
 
 #ifdef __cplusplus

@@ -299,6 +299,32 @@ def test_staged_and_plain_direct_kernels_are_identical(hip_ns, name):
             np.testing.assert_array_equal(out["staged"][0][k], out["plain"][0][k], err_msg="%s v%d %s" % (name, n, k))
 
 
+@pytest.mark.parametrize("variant", ["plain", "ref_step2_dxdy", "roi_inside"])
+def test_sample_stepping_on_the_tiled_path(hip_ns, port_ns, variant):
+    """Frames of one shape at different positions (sample stepping): the rectangle every frame contributes to runs on the
+    tiled path (per-frame positions folded into the staging addresses), the border strips on the general kernels
+    (path 4); a ROI inside the fully covered rectangle is the tiled path alone (path 2).  All against the CPU oracle."""
+    from umpa_amd.synth import make_stack
+    Nw, ms, K = 3, 4, 6
+    pos = [np.array(p) for p in [(0, 0), (0, 14), (9, 0), (9, 14), (4, 7), (0, 0)]]
+    frames = [make_stack(150, 170, 1, ms, df=True, seed=300 + k, amplitude=2.0) for k in range(K)]
+    sam = [np.ascontiguousarray(f[0][0]) for f in frames]
+    ref = [np.ascontiguousarray(f[1][0]) for f in frames]
+    kw = dict(window_size=Nw, max_shift=ms, pos_list=pos)
+    g, o = hip_ns.UMPAModelDF(sam, ref, **kw), port_ns.UMPAModelDF(sam, ref, **kw)
+    mk = dict(quiet=True)
+    if variant == "ref_step2_dxdy":
+        g.assign_coordinates = o.assign_coordinates = "ref"
+        mk.update(step=2, dxdy=(1, -1))
+    elif variant == "roi_inside":
+        mk.update(ROI=((12, 120, 1), (16, 150, 1)))
+    got, want = g.match(**mk), o.match(**mk)
+    assert g._lib.last_path(g._handle) == (2 if variant == "roi_inside" else 4)
+    st = assert_parity(got, want, ms, "stepping tiled %s" % variant)
+    assert st["ok"] > 1000
+    np.testing.assert_array_equal(g.coverage(), o.coverage())
+
+
 def test_plain_c_host_of_the_c_abi(hip_ns, tmp_path):
     """examples/c_host.c: the boundary is a C ABI -- a host with no Python and no PyTorch in the process."""
     import subprocess

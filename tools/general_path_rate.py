@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rate of the general (non-tiled) path on one GPU, device-resident: BASELINE config C2's stack (a) forced onto the
 general kernels, (b) with a 95 % random mask, (c) as a 2 x 2 sample-stepping stack (four positions, 2 or 3 frames each).
-Each with the staged kernel (windows out of LDS) and with the plain one (windows through L1)."""
+Each as the library routes it ("auto": the tiled path where it applies -- for the stepping stack on the rectangle every
+frame contributes to, path 4), with the staged general kernel (windows out of LDS) and with the plain one (through L1)."""
 import ctypes, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,7 +37,7 @@ for name, c in cases.items():
         cm = m.coverage()
         cover = torch.from_numpy(cm).to(dev)
         thr = .1 * cm.max() / K
-    for tag, flags in (("staged", _lib.F_FORCE_DIRECT), ("plain", _lib.F_FORCE_DIRECT | _lib.F_FORCE_PLAIN_DIRECT)):
+    for tag, flags in (("auto", 0), ("staged", _lib.F_FORCE_DIRECT), ("plain", _lib.F_FORCE_DIRECT | _lib.F_FORCE_PLAIN_DIRECT)):
         def step():
             rc = lib.match_region(h, 0, 1, N0, 0, 1, N1, values.data_ptr(), 5, None, err.data_ptr(),
                                   cover.data_ptr() if cover is not None else None, float(thr), None, None, None,

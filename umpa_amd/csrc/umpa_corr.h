@@ -56,6 +56,7 @@ struct CorrArgs {
     int N1;
     int sigma;                // +1: B = ref sits at p+u ('sam' mode); -1: B = sam sits at p-u ('ref' mode)
     int ntx, nty;
+    int br0, br1, bc0, bc1, Wf;   // rows / columns of the image inside every frame, the frames' common width (Maps, umpa_tiled.h)
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE): 1 no global loads, 4 no products, 8 no filters
 };
 
@@ -148,7 +149,6 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
     const int grp = UI > 1 ? __builtin_amdgcn_readfirstlane(tid / NTG) : 0, gtid = tid - grp * NTG;
     const int prow0 = A.row0 + ty * C::TR, pcol0 = tx * TC;           // first output pixel of the tile (region coords)
     const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
-    const int H = gp(m.frames)->H, W = gp(m.frames)->W;
     const int oi0 = (pass / nbatch) * UI - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
 
     // ---- LDS-DMA slots of this thread: piece p = tid + n*NT of the frame image (A rows, then B rows); its source
@@ -166,16 +166,17 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
             const int q = min(p - C::QR * C::PA, C::QRB * C::PB - 1);
             r = q / C::PB + oi0; c = 2 * (q % C::PB) + oj0;
         }
-        const int gr = min(max(fr0 + r, 0), H - 1), gc = min(max(fc0 + c, 0), W - 2);
-        src_off[n] = (unsigned)(gr * W + gc) * 8u;
+        const int gr = min(max(fr0 + r, A.br0), A.br1), gc = min(max(fc0 + c, A.bc0), A.bc1 - 1);
+        src_off[n] = (unsigned)(gr * A.Wf + gc) * 8u;
         if (isB) src_isB |= 1u << n;
     }
     const unsigned wave_piece0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);   // first piece of this wave's instruction 0
 
     auto issue_frame = [&](int k) {                                   // frame k -> ring slot k % NSLOT
         const FrameDesc fd = load_frame(m.frames, k);
-        const UMPA_GLOBAL char* gA = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fd.sam : fd.ref);
-        const UMPA_GLOBAL char* gB = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fd.ref : fd.sam);
+        const long shift = ((long)fd.pi * A.Wf + fd.pj) * 8;          // image coordinates -> this frame's array, bytes
+        const UMPA_GLOBAL char* gA = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fd.sam : fd.ref) - shift;
+        const UMPA_GLOBAL char* gB = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fd.ref : fd.sam) - shift;
         UMPA_LDS_AS char* slot = (UMPA_LDS_AS char*)(lds + (k % C::NSLOT) * C::SLOT);
 #pragma unroll
         for (int n = 0; n < C::NPT; n++) {

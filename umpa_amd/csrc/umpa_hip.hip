@@ -91,6 +91,7 @@ struct umpa_hip_model {
     int rows_piece_rows = 0;
     FrameDesc* h_desc = nullptr;                   // pinned host copy of the descriptor table (source of the stream-ordered update)
     DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small, b_kern;
+    DevBuf t_values, t_uv, t_err, t_cover, t_dd, t_da, t_dn;   // dense outputs of a sub-rectangle (sample-stepping split)
     TiledState tiled;                              // scratch of the tiled fast path
     int last_path = 0;
     bool timing = false;
@@ -327,14 +328,13 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
     return 0;
 }
 
-// Can the tiled fast path take this region?  (see umpa_tiled.h for what it covers)
+// Can the tiled fast path take this model and region?  (see umpa_tiled.h for what it covers; frame positions are
+// dealt with by run_match)
 bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
 {
     if (m->has_mask || m->kind == UMPA_HIP_KIND_DFKERNEL) return false;
-    for (int k = 0; k < m->Na; k++) {
-        if (m->pos[2 * k] || m->pos[2 * k + 1]) return false;
+    for (int k = 0; k < m->Na; k++)
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
-    }
     // stepped regions: the tiled kernels still compute the dense grid, which pays while step0*step1 is small
     // (the direct kernel's cost is per requested pixel, about 20x the tiled cost per dense pixel)
     if (A.step0 * A.step1 > 9) return false;
@@ -347,21 +347,129 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
     return tiled_supported(m->Nw, m->ms, m->Na);
 }
 
+// Frames of one shape at different positions (sample stepping, Model.cpp:428-433 / :716-719): the image they tile,
+// the box of image rows / columns that lie inside every frame, and the rectangle [a0,b0) x [a1,b1) of region pixels
+// that every frame contributes to (coverage = Na there, so those pixels see exactly the all-frames sums the tiled
+// kernels form).
+struct StepGeom { bool any_pos; int Himg, Wimg; FrameBox box; int a0, b0, a1, b1; };
+
+StepGeom step_geometry(const umpa_hip_model* m, const RegionArgs& A)
+{
+    StepGeom g;
+    g.any_pos = false;
+    int r0 = 0, r1 = 1 << 30, c0 = 0, c1 = 1 << 30;
+    g.Himg = g.Wimg = 0;
+    for (int k = 0; k < m->Na; k++) {
+        const int pi = m->pos[2 * k], pj = m->pos[2 * k + 1], H = m->dims[2 * k], W = m->dims[2 * k + 1];
+        if (pi || pj) g.any_pos = true;
+        r0 = std::max(r0, pi); r1 = std::min(r1, pi + H - 1);
+        c0 = std::max(c0, pj); c1 = std::min(c1, pj + W - 1);
+        g.Himg = std::max(g.Himg, pi + H); g.Wimg = std::max(g.Wimg, pj + W);
+    }
+    g.box.r0 = r0; g.box.r1 = r1; g.box.c0 = c0; g.box.c1 = c1; g.box.Wf = m->dims[1];
+    // a frame contributes at image pixel (i, j) iff i - pi - pad >= 0 and i - pi + pad <= H (same for j)
+    const int pad = m->padding;
+    // (the last contributing column, j = c1 + 1 - pad, would make corr_volume read the very last column of a frame as the
+    // first half of a 16-byte column pair: it is left to the border strip)
+    const int imin = r0 + pad, imax = r1 + 1 - pad, jmin = c0 + pad, jmax = c1 - pad;
+    auto lo = [](int vmin, int org, int step, int N) { int q = vmin - org; q = q <= 0 ? 0 : (q + step - 1) / step; return std::min(q, N); };
+    auto hi = [](int vmax, int org, int step, int N) { int q = vmax - org; q = q < 0 ? 0 : q / step + 1; return std::min(q, N); };
+    g.a0 = lo(imin, A.org0, A.step0, A.N0); g.b0 = std::max(g.a0, hi(imax, A.org0, A.step0, A.N0));
+    g.a1 = lo(jmin, A.org1, A.step1, A.N1); g.b1 = std::max(g.a1, hi(jmax, A.org1, A.step1, A.N1));
+    return g;
+}
+
+int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int flags, hipStream_t s,
+              int piece_rows, const std::function<void(int, int)>& on_rows)
+{
+    TiledTimers tt;
+    tt.get = [m]() { return get_event(m); };
+    int rc = tiled_match(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
+                         m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
+    if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
+    if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
+    for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; m->launches.push_back(tl); }
+    return 0;
+}
+
+// copy a block of pixels (rows x cols, `epp` bytes per pixel) between two row-major pixel arrays on the device
+hipError_t copy_block(void* dst, int dN1, int dr, int dc, const void* src, int sN1, int sr, int sc,
+                      int rows, int cols, size_t epp, hipStream_t s)
+{
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    return hipMemcpy2DAsync((char*)dst + ((size_t)dr * dN1 + dc) * epp, (size_t)dN1 * epp,
+                            (const char*)src + ((size_t)sr * sN1 + sc) * epp, (size_t)sN1 * epp,
+                            (size_t)cols * epp, (size_t)rows, hipMemcpyDeviceToDevice, s);
+}
+
+// One sub-rectangle [r0,r1) x [c0,c1) of the region, matched into dense scratch arrays and copied back: `tiled` sends
+// it down the tiled path (every frame contributes everywhere in it), otherwise the general kernels take it.
+int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0, int r1, int c0, int c1, bool tiled,
+              int flags, hipStream_t s)
+{
+    const int rows = r1 - r0, cols = c1 - c0;
+    if (rows <= 0 || cols <= 0) return 0;
+    const size_t n = (size_t)rows * cols, nfull = (size_t)A.N0 * A.N1;
+    const bool planar = A.v_px == 1 && A.nparam > 1;
+    const int np = A.nparam;
+    if (m->t_values.reserve(n * np * sizeof(double)) || m->t_err.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "block scratch");
+    RegionArgs B = A;
+    B.org0 = A.org0 + A.step0 * r0; B.N0 = rows;
+    B.org1 = A.org1 + A.step1 * c0; B.N1 = cols;
+    B.values = (double*)m->t_values.p; B.err = (int*)m->t_err.p;
+    B.v_px = planar ? 1 : (size_t)np; B.v_k = planar ? n : 1;
+    B.uv = nullptr; B.cover = nullptr; B.dbg_d = nullptr; B.dbg_a = nullptr; B.dbg_n = nullptr;
+    hipError_t e = hipSuccess;
+    auto in = [&](void* t, const void* full, size_t epp) { if (e == hipSuccess) e = copy_block(t, cols, 0, 0, full, A.N1, r0, c0, rows, cols, epp, s); };
+    auto out = [&](void* full, const void* t, size_t epp) { if (e == hipSuccess) e = copy_block(full, A.N1, r0, c0, t, cols, 0, 0, rows, cols, epp, s); };
+    // what the kernels may leave untouched (pixels below the coverage threshold) must come back as it was
+    if (!tiled) {
+        if (planar) for (int k = 0; k < np; k++) in(B.values + (size_t)k * n, A.values + (size_t)k * nfull, sizeof(double));
+        else in(B.values, A.values, np * sizeof(double));
+        in(B.err, A.err, sizeof(int));
+    }
+    if (A.uv) { if (m->t_uv.reserve(n * 2 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.uv = (double*)m->t_uv.p; in(B.uv, A.uv, 2 * sizeof(double)); }
+    if (A.cover && !tiled) { if (m->t_cover.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); in(m->t_cover.p, A.cover, sizeof(double)); B.cover = (const double*)m->t_cover.p; }
+    if (A.dbg_d) { if (m->t_dd.reserve(n * 25 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_d = (double*)m->t_dd.p; if (!tiled) in(B.dbg_d, A.dbg_d, 25 * sizeof(double)); }
+    if (A.dbg_a) { if (m->t_da.reserve(n * 16 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_a = (double*)m->t_da.p; if (!tiled) in(B.dbg_a, A.dbg_a, 16 * sizeof(double)); }
+    if (A.dbg_n) { if (m->t_dn.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_n = (int*)m->t_dn.p; if (!tiled) in(B.dbg_n, A.dbg_n, sizeof(int)); }
+    if (e != hipSuccess) return fail(UMPA_HIP_E_DEVICE, "block gather: %s", hipGetErrorString(e));
+    if (int rc = tiled ? run_tiled(m, B, g, flags, s, 0, nullptr) : run_direct(m, B, s, flags)) return rc;
+    if (planar) for (int k = 0; k < np; k++) out(A.values + (size_t)k * nfull, B.values + (size_t)k * n, sizeof(double));
+    else out(A.values, B.values, np * sizeof(double));
+    out(A.err, B.err, sizeof(int));
+    if (A.uv) out(A.uv, B.uv, 2 * sizeof(double));
+    if (A.dbg_d) out(A.dbg_d, B.dbg_d, 25 * sizeof(double));
+    if (A.dbg_a) out(A.dbg_a, B.dbg_a, 16 * sizeof(double));
+    if (A.dbg_n) out(A.dbg_n, B.dbg_n, sizeof(int));
+    if (e != hipSuccess) return fail(UMPA_HIP_E_DEVICE, "block scatter: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
               int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
 {
     const bool can_tile = tiled_applicable(m, A);
-    if ((flags & UMPA_HIP_F_FORCE_TILED) && !can_tile)
+    const StepGeom g = can_tile ? step_geometry(m, A) : StepGeom();
+    const bool whole = can_tile && (!g.any_pos || (g.a0 == 0 && g.b0 == A.N0 && g.a1 == 0 && g.b1 == A.N1));
+    // sample stepping: the tiled path takes the rectangle every frame contributes to, the general kernels the border
+    // strips around it -- worth the split while the rectangle is most of the region
+    const bool split = can_tile && !whole && (size_t)(g.b0 - g.a0) * (g.b1 - g.a1) * 2 >= (size_t)A.N0 * A.N1;
+    if ((flags & UMPA_HIP_F_FORCE_TILED) && !(whole || split))
         return fail(UMPA_HIP_E_UNSUPPORTED, "tiled path does not cover this model/region");
-    if (can_tile && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
-        TiledTimers tt;
-        tt.get = [m]() { return get_event(m); };
-        int rc = tiled_match(m->tiled, m->dev(), m->kind, m->dims[0], m->dims[1], A, s,
-                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
-        if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
-        if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
-        for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; m->launches.push_back(tl); }
+    if (whole && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
+        if (int rc = run_tiled(m, A, g, flags, s, piece_rows, on_rows)) return rc;
         m->last_path = 2;
+        return 0;
+    }
+    if (split && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
+        if (int rc = run_block(m, A, g, g.a0, g.b0, g.a1, g.b1, true, flags, s)) return rc;           // centre: tiled
+        if (int rc = run_block(m, A, g, 0, g.a0, 0, A.N1, false, flags, s)) return rc;                 // top strip
+        if (int rc = run_block(m, A, g, g.b0, A.N0, 0, A.N1, false, flags, s)) return rc;              // bottom strip
+        if (int rc = run_block(m, A, g, g.a0, g.b0, 0, g.a1, false, flags, s)) return rc;              // left strip
+        if (int rc = run_block(m, A, g, g.a0, g.b0, g.b1, A.N1, false, flags, s)) return rc;           // right strip
+        if (on_rows) on_rows(0, A.N0);
+        m->last_path = 4;
         return 0;
     }
     const int rc = run_direct(m, A, s, flags);
@@ -611,6 +719,7 @@ void umpa_hip_destroy(umpa_hip_model* m)
     tiled_release(m->tiled);
     m->b_values.release(); m->b_uv.release(); m->b_err.release(); m->b_cover.release();
     m->b_dd.release(); m->b_da.release(); m->b_dn.release(); m->b_small.release(); m->b_kern.release();
+    m->t_values.release(); m->t_uv.release(); m->t_err.release(); m->t_cover.release(); m->t_dd.release(); m->t_da.release(); m->t_dn.release();
     if (m->d_desc) (void)hipFree(m->d_desc);
     if (m->d_win) (void)hipFree(m->d_win);
     if (m->d_frames_blob) (void)hipFree(m->d_frames_blob);

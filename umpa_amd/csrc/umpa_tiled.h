@@ -38,7 +38,11 @@ struct Maps {                        // prep_maps outputs, each a full H x W pla
     double* RefSq;                   // sum_k W[r_k^2]                      -> t3
     double* WS;                      // [K] planes W[s_k]                           (DF)
     double* MR;                      // [K] planes mean_k = W[r_k]/sum(w)           (DF)
-    int H, W;
+    int H, W;                        // plane size = extent of the image the frames tile (max over frames of position + shape)
+    // Frames of one shape at different positions (sample stepping): rows / columns of the image that lie inside EVERY
+    // frame (patch reads are clamped to this box; inside the fully covered region nothing is clamped), and the frames'
+    // common width.  Frame k's pixel (row, col) of the image is element (row - pi_k) * Wf + (col - pj_k) of its array.
+    int br0, br1, bc0, bc1, Wf;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -86,19 +90,19 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
     constexpr int NS = (C::Q * C::Q + C::NT - 1) / C::NT;
     int s_lds[NS], s_g[NS];
     {
-        const int Hf = gp(m.frames)->H, Wf = gp(m.frames)->W;          // tiled path: all frames share one shape
 #pragma unroll
         for (int n = 0; n < NS; n++) {
             const int it = tid + n * C::NT, c = it % C::Q, r = it / C::Q;
             s_lds[n] = it < C::Q * C::Q ? c * C::QP + r : -1;
-            s_g[n] = min(r0 - NW + r, Hf - 1) * Wf + min(c0 - NW + c, Wf - 1);
+            s_g[n] = min(max(r0 - NW + r, M.br0), M.br1) * M.Wf + min(max(c0 - NW + c, M.bc0), M.bc1);
         }
     }
     double ps[NS], pr[NS];
     auto fetch = [&](int k) {
         const FrameDesc f = load_frame(m.frames, k);
+        const long shift = (long)f.pi * M.Wf + f.pj;                  // image coordinates -> this frame's array
 #pragma unroll
-        for (int n = 0; n < NS; n++) { ps[n] = gp(f.sam)[s_g[n]]; pr[n] = do_ref ? gp(f.ref)[s_g[n]] : 0.0; }
+        for (int n = 0; n < NS; n++) { ps[n] = gp(f.sam)[s_g[n] - shift]; pr[n] = do_ref ? gp(f.ref)[s_g[n] - shift] : 0.0; }
     };
     fetch(0);
     for (int k = 0; k < m.Na; k++) {
@@ -527,7 +531,9 @@ inline size_t tiled_table_budget()
 // `piece_rows` > 0: row chunks of at most that many dense rows (a multiple of 32) even where the table budget would
 // allow more (the host-array entry point downloads the rows of chunk c while chunk c+1 is being matched, the multi-GPU
 // leg sends them to rank 0); `on_rows(xi_lo, xi_hi)` is called after the kernels of a chunk have been enqueued.
-inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const RegionArgs& A,
+struct FrameBox { int r0, r1, c0, c1, Wf; };
+
+inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const FrameBox& box, const RegionArgs& A,
                        hipStream_t s, TiledTimers* tt, bool reuse_ref_maps,
                        int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
 {
@@ -544,6 +550,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     if (st.ref_kind != kind || st.ref_K != K || st.ref_plane != plane) st.ref_maps_ok = false;
     Maps M;
     M.H = H; M.W = W;
+    M.br0 = box.r0; M.br1 = box.r1; M.bc0 = box.c0; M.bc1 = box.c1; M.Wf = box.Wf;
     M.SamSq = st.maps; M.RefSq = st.maps + plane;
     M.WS = kind == 1 ? st.maps + 2 * plane : nullptr;
     M.MR = kind == 1 ? st.maps + (2 + (size_t)K) * plane : nullptr;
@@ -608,6 +615,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         CA.table = st.table; CA.slot_stride = (size_t)drows * N1d;
         CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = drow0; CA.rows = drows; CA.N1 = N1d;
         CA.sigma = dev.ref_mode ? -1 : 1;
+        CA.br0 = box.r0; CA.br1 = box.r1; CA.bc0 = box.c0; CA.bc1 = box.c1; CA.Wf = box.Wf;
         { const char* ab = getenv("UMPA_HIP_ABLATE"); CA.ablate = ab ? atoi(ab) : 0; }
         CA.ntx = CA.nty = 0;                                          // set by launch_corr for the tile shape it picks
         e = hipErrorInvalidValue;
