@@ -49,7 +49,9 @@ extern "C" {
 /* create flags */
 #define UMPA_HIP_F_DEVICE_FRAMES  1  /* sam/ref/mask pointers are device pointers on `device`; borrowed, not copied */
 /* match flags */
-#define UMPA_HIP_F_DEVICE_IO      1  /* values/uv/err/covermap/debug pointers are device pointers; call is async on `stream` */
+#define UMPA_HIP_F_DEVICE_IO      1  /* values/uv/err/covermap/debug pointers are device pointers; the call only enqueues work on `stream`
+                                        and returns: the results are valid, and a kernel fault surfaces, when the caller
+                                        synchronises that stream (hipStreamSynchronize / an event), as with any launch */
 #define UMPA_HIP_F_FORCE_DIRECT   2  /* use the general direct kernel even where the tiled fast path applies */
 #define UMPA_HIP_F_FORCE_TILED    4  /* fail with E_UNSUPPORTED instead of silently using the direct kernel */
 #define UMPA_HIP_F_PLANAR         8  /* values is [nparam][N0*N1] (one plane per map) instead of the reference's [N0*N1][nparam] */

@@ -393,8 +393,8 @@ inline int pick_ub(int UJ)
 {
     // batch width over the column shifts: fewest batches (each batch re-stages the frames), then least padding
     int best = 5, best_nb = 1 << 30, best_waste = 1 << 30;
-    const int cand[3] = {9, 7, 5};
-    for (int q = 0; q < 3; q++) {
+    const int cand[4] = {9, 8, 7, 5};
+    for (int q = 0; q < 4; q++) {
         const int ub = cand[q], nb = (UJ + ub - 1) / ub, w = nb * ub - UJ;
         if (nb < best_nb || (nb == best_nb && w < best_waste)) { best = ub; best_nb = nb; best_waste = w; }
     }
@@ -471,6 +471,10 @@ inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A,
 {
     if (ub == 9) {
         if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s, fma);
+        ub = 8;
+    }
+    if (ub == 8) {
+        if constexpr (CorrCfg<NW, 8, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 8>(dev, A, sep, s, fma);
         ub = 7;
     }
     if (ub == 7) {

@@ -22,7 +22,7 @@ Two input situations are covered:
 import numpy as np
 
 __all__ = ["slab_bounds", "input_rows", "match_rows", "exchange_halo", "gather_rows",
-           "RowShardedStack", "exchange_halos", "gather_slabs", "send_rows_to", "slab_piece_bounds"]
+           "RowShardedStack", "exchange_halos", "gather_slabs", "send_rows_to"]
 
 
 def slab_bounds(n_rows, world, rank):
@@ -272,12 +272,3 @@ def send_rows_to(tensors, wholes, n_rows, lo, hi, dst=0, group=None):
             view.copy_(buf)
         return []
     return works
-
-
-def slab_piece_bounds(n_rows, world, pieces):
-    """The (lo, hi) sequence ``send_rows_to`` must see on every rank when the pieces are announced by a callback whose
-    boundaries depend on the rank's slab size: not used by bench.py (the library announces the same boundaries for
-    slabs that differ by one row only in the last piece), kept for hosts that cut the pieces themselves."""
-    biggest = max(b - a for a, b in (slab_bounds(n_rows, world, g) for g in range(world)))
-    step = -(-biggest // pieces)
-    return [(r, min(r + step, biggest)) for r in range(0, biggest, step)]
