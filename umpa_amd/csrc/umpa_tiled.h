@@ -448,11 +448,13 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 
 // Workgroup shapes, first that fits (UMPA_HIP_CORR_SHAPE picks one by number):
 //   id: tile columns, threads per group, groups (row offsets per pass), workgroups per CU, flush rounds.
-// Measured on C2 (ms per match, round 2): 32x16 tiles / 256 threads / 2 per CU 2.12; the same with 3 per CU and two
-// flush rounds 2.05-2.18; 320 or 384 threads 2.26-2.40; two or three row offsets per pass sharing one staging
-// (512 / 768 threads, one workgroup per CU) 2.33 / 3.5-4.6 (the latter spills).  C3: 32x32 / 512 / 1 per CU 40.5-43.4,
-// 384 threads 46.1.  Only the two winners are instantiated.
-#define UMPA_CORR_SHAPES(X) X(1, 16, 256, 1, 2, 1) X(2, 32, 512, 1, 1, 1)
+// Measured on C2 (ms per corr_volume, round 2): 32x32 tiles / 256 threads (8-wide register blocks) / 2 per CU with the
+// planes flushed in three rounds 1.86-1.90, in two rounds 1.93; 32x16 tiles / 256 threads / 2 per CU 2.12-2.18; the
+// same with 3 per CU and two flush rounds 2.05-2.18; 32x32 with 320 or 384 threads at 2 per CU 2.99-3.46 (168-register
+// cap, spills); two or three row offsets per pass sharing one staging (512 / 768 threads, one workgroup per CU) 2.33 /
+// 3.5-4.6.  C3 (window 15, 32x32 / 256 does not hold the halo rows): 32x32 / 512 / 1 per CU 40.5-43.4, 384 threads
+// 46.1-51.6.  Only the winners are instantiated.
+#define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 3) X(2, 16, 256, 1, 2, 1) X(3, 32, 512, 1, 1, 1)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
 {
