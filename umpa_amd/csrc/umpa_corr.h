@@ -18,6 +18,7 @@
 // window's column filter in place and its row filter on the way to the table, as before.
 #pragma once
 #include "umpa_direct.h"
+#include <type_traits>
 
 namespace umpa {
 
@@ -204,12 +205,26 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         for (int f = 0; f < D; f++)
             if (f < K) issue_frame(f);
     }
-    for (int k = 0; k < K; k++) {
+    // One frame step.  ISSUE: frame k+D exists and its DMA instructions go out BETWEEN the product rows of frame k, one
+    // per QB-th of the FMAs (straight-line code, pinned with sched_barrier): a wave that issues them all at once sits in
+    // the issue queue of the memory pipeline instead of multiplying.
+    const bool dma = !(A.ablate & 1), prod = pactive && !(A.ablate & 4);
+    auto frame_step = [&](int k, auto ISSUE, auto DRAIN) {
         // frames k .. k+D-1 have been issued, in order: frame k has landed when at most (D-1)*NPT are outstanding
-        if (k + D - 1 < K) wait_vmcnt<(D - 1) * C::NPT>(); else wait_vmcnt<0>();
+        if constexpr (decltype(DRAIN)::value) wait_vmcnt<0>(); else wait_vmcnt<(D - 1) * C::NPT>();
         lds_barrier();                                                // everyone's pieces of frame k are in; slot (k-1)%NSLOT is free
-        if (k + D < K && !(A.ablate & 1)) issue_frame(k + D);
-        if (pactive && !(A.ablate & 4)) {
+        constexpr bool issue = decltype(ISSUE)::value;
+        const FrameDesc fdn = load_frame(m.frames, issue ? k + D : k);
+        const long shiftn = ((long)fdn.pi * A.Wf + fdn.pj) * 8;
+        const UMPA_GLOBAL char* gAn = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fdn.sam : fdn.ref) - shiftn;
+        const UMPA_GLOBAL char* gBn = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fdn.ref : fdn.sam) - shiftn;
+        UMPA_LDS_AS char* slotn = (UMPA_LDS_AS char*)(lds + ((k + D) % C::NSLOT) * C::SLOT);
+        auto issue_piece = [&](int n) {
+            const UMPA_GLOBAL char* src = ((src_isB >> n) & 1u ? gBn : gAn) + src_off[n];
+            __builtin_amdgcn_global_load_lds(src, slotn + (size_t)(wave_piece0 + n * NT) * 16, 16, 0, 0);
+        };
+        constexpr int PER = (C::NPT + C::QB - 1) / C::QB;            // DMA instructions per product row
+        if (prod) {
             const pair_t* img = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT);
             const pair_t* la = img + pr * C::PA + pqb * (C::QB / 2);
             const pair_t* lb = img + C::QR * C::PA + (pr + grp) * C::PB + pqb * (C::QB / 2);
@@ -219,9 +234,30 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
 #pragma unroll
             for (int t = 0; t < C::NBP; t++) bv[t] = lb[t];
 #pragma unroll
-            for (int t = 0; t < C::QB; t++)
+            for (int t = 0; t < C::QB; t++) {
+                if constexpr (issue) {
+#pragma unroll
+                    for (int q = 0; q < PER; q++)
+                        if (t * PER + q < C::NPT) issue_piece(t * PER + q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int u = 0; u < UB; u++) acc[t][u] = fma(av[t >> 1][t & 1], bv[(t + u) >> 1][(t + u) & 1], acc[t][u]);
+                if constexpr (issue) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (issue) {
+#pragma unroll
+            for (int n = 0; n < C::NPT; n++) issue_piece(n);
+        }
+    };
+    {
+        int k = 0;
+        if (dma) for (; k + D < K; k++) frame_step(k, std::true_type{}, std::false_type{});
+        // the last D frames (all frames without DMA): nothing left to issue; once fewer than D frames are outstanding
+        // the counted wait would be too lax, so these steps drain
+        for (; k < K; k++) {
+            if (k + D - 1 < K && dma) frame_step(k, std::false_type{}, std::false_type{});
+            else frame_step(k, std::false_type{}, std::true_type{});
         }
     }
     if (A.ablate & 8) return;
