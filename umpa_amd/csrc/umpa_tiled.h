@@ -66,7 +66,10 @@ struct PrepCfg {
 };
 
 template <int KIND, int NW>
-__global__ void __launch_bounds__(256)
+#ifndef UMPA_PREP_WPS
+#define UMPA_PREP_WPS 2
+#endif
+__global__ void __launch_bounds__(256, UMPA_PREP_WPS)
 prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
 {
     // sides: bit 0 = the sample-side maps (SamSq, WS_k), bit 1 = the reference-side maps (RefSq, MR_k).
@@ -88,9 +91,11 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
     // V-stage ownership: item = (sq, rb, c), c fastest: 2 planes x 4 row blocks x 32 columns = 256 items, one per
     // thread and stack (wave-uniform sq).  acc[st]: sums over the frames for stack st (0 sample, 1 reference).
     const int vc = tid & 31, vrb = (tid >> 5) & 3, vsq = tid >> 7;
-    double acc[2][C::CB], held[2][C::CB];
+    // one register set for both roles: the threads of the squares (vsq = 1) sum over the frames in it, the threads of
+    // the values (vsq = 0) park the even frame of a pair in it
+    double acc[2][C::CB];
 #pragma unroll
-    for (int o = 0; o < C::CB; o++) acc[0][o] = acc[1][o] = held[0][o] = held[1][o] = 0.0;
+    for (int o = 0; o < C::CB; o++) acc[0][o] = acc[1][o] = 0.0;
 
     // staging slots of this thread: compile-time count, so the frame k+1 can wait in registers while frame k is filtered
     constexpr int NS = (C::Q * C::Q + C::NT - 1) / C::NT;
@@ -163,12 +168,12 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
                         const double v = st == 0 ? out[o] : out[o] / m.win_sum;                  // Model.cpp:739
                         if (odd) {
                             if (inside) {
-                                map_pair_t pv; pv[0] = held[st][o]; pv[1] = v;
+                                map_pair_t pv; pv[0] = acc[st][o]; pv[1] = v;
                                 *reinterpret_cast<UMPA_GLOBAL map_pair_t*>(dstmap + map_at(k - 1, (size_t)gr * M.W + gc, plane)) = pv;
                             }
                         } else if (last) {
                             if (inside) dstmap[map_at(k, (size_t)gr * M.W + gc, plane)] = v;
-                        } else held[st][o] = v;
+                        } else acc[st][o] = v;
                     }
                 }
             }
