@@ -78,7 +78,10 @@ struct CorrCfg {
     static constexpr int QR = TR + 2 * NW, QC = TC + 2 * NW;  // q-region (tile + window halo): rows, columns
     static constexpr int QRB = QR + UI - 1;               // rows of the B image
     static constexpr int QP = QR | 1;                     // odd pitch of the transposed product planes ([column][row])
-    static constexpr int PPL = QC * QP;                   // one product plane
+    // one product plane; padded so that PPL = QR (mod 32): the column filter's lanes run over the rows of one
+    // (plane, column block) after the other, plane fastest, and with this pitch the LDS bank sequence continues
+    // across the seam between two runs (a 32-lane group never meets a bank twice)
+    static constexpr int PPL = QC * QP + ((QR - QC * QP) % 32 + 32) % 32;
     // product blocking: a thread owns one q row and QB consecutive columns (QB even: column pairs)
     static constexpr int QB = (QR * ((QC + 3) / 4) <= NTG) ? 4 : (QR * ((QC + 5) / 6) <= NTG) ? 6 : 8;
     static constexpr int NQB = (QC + QB - 1) / QB;        // column blocks
@@ -108,6 +111,15 @@ typedef double table_pair_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_table16(UMPA_GLOBAL double* dst, table_pair_t v)
 {
     *reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst) = v;
+}
+
+// the value of the lane whose number differs in bit 0 (DPP quad_perm [1,0,3,2]: no LDS crossbar, unlike __shfl_xor)
+__device__ __forceinline__ double swap_adjacent_lanes(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
 
 template <int N>
@@ -264,7 +276,7 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
     // ---- all frames of this pass are in.  Plane P = g*UB + u of the pass; round f puts planes [f*PR, (f+1)*PR) into
     // LDS (transposed, [column][row]), filters them along the columns in place and along the rows on the way out.
     const int nu = min(UB, ms - oj0);                                 // column offsets oj0 .. oj0+nu-1 are real
-    constexpr int PR = C::PR, VP = TC / 2, VITEMS2 = PR * (C::TR / C::CB) * VP, VROUNDS2 = (VITEMS2 + NT - 1) / NT;
+    constexpr int PR = C::PR, VITEMS2 = PR * (C::TR / C::CB) * TC, VROUNDS2 = (VITEMS2 + NT - 1) / NT;
     const bool vec_ok = (A.N1 & 1) == 0;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
@@ -288,7 +300,7 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         for (int rd = 0; rd < C::HROUNDS; rd++) {
             const int it = tid + rd * NT;
             if (it < C::HITEMS) {
-                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
+                const int r = it % C::QR, rest = it / C::QR, u = rest % PR, cb = rest / PR;
                 fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
             }
         }
@@ -297,43 +309,50 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
         for (int rd = 0; rd < C::HROUNDS; rd++) {
             const int it = tid + rd * NT;
             if (it < C::HITEMS) {
-                const int r = it % C::QR, rest = it / C::QR, cb = rest % (TC / C::CB), u = rest / (TC / C::CB);
+                const int r = it % C::QR, rest = it / C::QR, u = rest % PR, cb = rest / PR;
                 double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
 #pragma unroll
                 for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
             }
         }
         __syncthreads();
-        // V stage (along rows) and store: items (plane, rb, column pair), pair fastest -> coalesced table rows, and two
-        // adjacent columns per lane so that the table is written with 16-byte stores (twice the rate of 8-byte ones).
-        // Odd N1 breaks the 16-byte alignment of the rows: then the two columns are stored separately.
+        // V stage (along rows) and store: items (plane, rb, column), column fastest: the lanes of a 32-lane group read
+        // 32 columns at the odd pitch QP (16 columns x two row blocks 16 rows apart on 16-column tiles): no bank is met
+        // twice.  Two lanes with adjacent columns then swap half of their rows (DPP) so that each writes 16-byte table
+        // entries (twice the rate of 8-byte stores): the even column's lane the even rows, the odd one the odd rows.
+        // Odd N1 breaks the 16-byte alignment of the table rows: then every lane stores its own column.
 #pragma unroll
         for (int rd = 0; rd < VROUNDS2; rd++) {
             const int it = tid + rd * NT;
             if (it < VITEMS2) {
-                const int cp = it % VP, rest = it / VP, rb = rest % (C::TR / C::CB), pl = rest / (C::TR / C::CB);
+                const int c = it % TC, rest = it / TC;
+                const int rbq = rest % (C::TR / C::CB), pl = rest / (C::TR / C::CB);
+                const int rb = TC == 16 ? ((rbq & 1) << 1) | (rbq >> 1) : rbq;     // 16-column tiles: row blocks 0,2,1,3
                 const int P = f * PR + pl, g = P / UB, u = P - g * UB;
                 if (P < C::NPL && u < nu && oi0 + g <= ms - 1) {
-                    const int c = 2 * cp;
-                    double out0[C::CB], out1[C::CB];
-                    fir_block<NW, C::CB>(lds + pl * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out0);
-                    fir_block<NW, C::CB>(lds + pl * C::PPL + (c + 1) * C::QP + rb * C::CB, 1, sep.hr, out1);
+                    double out[C::CB];
+                    fir_block<NW, C::CB>(lds + pl * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
                     const int ui = A.sigma * (oi0 + g), uj = A.sigma * (oj0 + u);
                     const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
                     const int col = pcol0 + c;
                     UMPA_GLOBAL double* dst = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 + rb * C::CB - A.row0) * A.N1 + col;
+                    if (vec_ok) {
+                        const int odd = c & 1;
 #pragma unroll
-                    for (int o = 0; o < C::CB; o++) {
-                        const int row = prow0 + rb * C::CB + o;               // region row
-                        if (row < A.row0 + A.rows) {
-                            if (vec_ok && col + 1 < A.N1) {
-                                pair_t v2; v2[0] = out0[o]; v2[1] = out1[o];
-                                store_table16(dst + (size_t)o * A.N1, v2);
-                            } else {
-                                if (col < A.N1) dst[(size_t)o * A.N1] = out0[o];
-                                if (col + 1 < A.N1) dst[(size_t)o * A.N1 + 1] = out1[o];
+                        for (int h = 0; h < C::CB / 2; h++) {
+                            const double mine = odd ? out[2 * h + 1] : out[2 * h];
+                            const double give = odd ? out[2 * h] : out[2 * h + 1];
+                            const double got = swap_adjacent_lanes(give);           // the neighbour column's value of MY row
+                            const int o = 2 * h + odd, row = prow0 + rb * C::CB + o;
+                            if (row < A.row0 + A.rows && col < A.N1) {
+                                pair_t v2; v2[0] = odd ? got : mine; v2[1] = odd ? mine : got;
+                                store_table16(dst + (size_t)o * A.N1 - odd, v2);
                             }
                         }
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < C::CB; o++)
+                            if (prow0 + rb * C::CB + o < A.row0 + A.rows && col < A.N1) dst[(size_t)o * A.N1] = out[o];
                     }
                 }
             }
