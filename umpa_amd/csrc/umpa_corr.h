@@ -105,12 +105,12 @@ struct CorrCfg {
                                LDS_DOUBLES * 8 <= LDSB && NTG % 64 == 0 && NT <= 1024 && WPS <= 8;
 };
 
-// 16-byte store of two table entries (an `sc1` store, which makes the XCD's L2 drop the line instead of keeping it,
-// was tried so that the 2.7 GB streaming out would not evict frame patches: no difference on C2, slower on C3)
+// 16-byte store of two table entries, non-temporal (`nt`): the 2.7 GB streaming out no longer push the frame patches
+// the other passes of the tile are about to re-read out of L2 (C2 1.94 -> 1.84 ms; an `sc1` store made no difference)
 typedef double table_pair_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_table16(UMPA_GLOBAL double* dst, table_pair_t v)
 {
-    *reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst));
 }
 
 // the value of the lane whose number differs in bit 0 (DPP quad_perm [1,0,3,2]: no LDS crossbar, unlike __shfl_xor)
