@@ -496,7 +496,8 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // 46.1-51.6.  Also tried on 32x32: two row offsets per pass (512 threads, 1 per CU) 2.16-2.30; 24-column tiles with a
 // three-frame ring 1.94-2.04.  Per workgroup and pass (s_memtime, 32x32 / 256 / 2 per CU): frame loop 37 k cycles,
 // flush 21 k (planes to LDS 3.5 k, column filter 5.2 k, write back 2.5 k, row filter + stores 9.6 k): every shape ends
-// near 30 k CU cycles per 1024 pixels and 9 planes.  Only the winners are instantiated.
+// near 30 k CU cycles per 1024 pixels and 9 planes.  C3 on 24-column tiles / 256 threads / 2 per CU: 39.2-39.9
+// against 38.2 on the same box.  Only the winners are instantiated.
 #define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 3) X(2, 16, 256, 1, 2, 1) X(3, 32, 512, 1, 1, 1)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
