@@ -99,6 +99,8 @@ def test_dfkernel_single_pixel_and_mask(hip_ns, port_ns):
     dict(H=101, W=67, K=2, Nw=6, ms=3, df=False, amp=0.3),
     dict(H=120, W=131, K=3, Nw=8, ms=5, df=True, amp=2.0),      # widest window the tiled path is built for
     dict(H=70, W=75, K=18, Nw=2, ms=4, df=True, amp=1.5),       # more frames than replay_walk keeps in registers     # 32x32-tile shape of the tiled path (Nw > 5), small search range
+    dict(H=64, W=72, K=25, Nw=2, ms=3, df=True, amp=1.0),       # odd frame count beyond the templated ones: generic replay_walk on the frame-pair maps
+    dict(H=64, W=70, K=26, Nw=3, ms=3, df=True, amp=1.0),       # even, same path
 ])
 def test_hip_matches_oracle_on_seeded_inputs(hip_ns, port_ns, cfg):
     from umpa_amd.synth import make_stack
