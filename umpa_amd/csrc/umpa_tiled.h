@@ -66,10 +66,9 @@ struct PrepCfg {
 };
 
 template <int KIND, int NW>
-#ifndef UMPA_PREP_WPS
-#define UMPA_PREP_WPS 2
-#endif
-__global__ void __launch_bounds__(256, UMPA_PREP_WPS)
+// three workgroups per CU where the window leaves the registers for it (C2: 0.42 -> 0.375 ms; at Nw = 7 the 168-register
+// cap spills and loses: C3 3.9 -> 4.3 ms)
+__global__ void __launch_bounds__(256, NW <= 5 ? 3 : 2)
 prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
 {
     // sides: bit 0 = the sample-side maps (SamSq, WS_k), bit 1 = the reference-side maps (RefSq, MR_k).
@@ -108,24 +107,27 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
             s_g[n] = min(max(r0 - NW + r, M.br0), M.br1) * M.Wf + min(max(c0 - NW + c, M.bc0), M.bc1);
         }
     }
-    double ps[NS], pr[NS];
-    auto fetch = [&](int k) {
+    // one patch waits in registers while the one before it is filtered: sample k, reference k, sample k+1, ...
+    double pp[NS];
+    auto fetch = [&](int k, int st) {
         const FrameDesc f = load_frame(m.frames, k);
         const long shift = (long)f.pi * M.Wf + f.pj;                  // image coordinates -> this frame's array
+        const UMPA_GLOBAL double* src = gp(st ? f.ref : f.sam);
 #pragma unroll
-        for (int n = 0; n < NS; n++) { ps[n] = gp(f.sam)[s_g[n] - shift]; pr[n] = do_ref ? gp(f.ref)[s_g[n] - shift] : 0.0; }
+        for (int n = 0; n < NS; n++) pp[n] = src[s_g[n] - shift];
     };
-    fetch(0);
+    fetch(0, 0);
     for (int k = 0; k < m.Na; k++) {
 #pragma unroll
         for (int st = 0; st < 2; st++) {                              // 0: sample patch, 1: reference patch
             if (st == 1 && !do_ref) break;
             __syncthreads();                                          // every reader of the LDS region is done
-            // stage the raw patch, transposed; the global reads (issued one frame ahead) are coalesced along columns
+            // stage the raw patch, transposed; the global reads (issued one patch ahead) are coalesced along columns
 #pragma unroll
             for (int n = 0; n < NS; n++)
-                if (s_lds[n] >= 0) raw[s_lds[n]] = st ? pr[n] : ps[n];
-            if (st == (do_ref ? 1 : 0) && k + 1 < m.Na) fetch(k + 1);  // both patches of frame k are out of the registers
+                if (s_lds[n] >= 0) raw[s_lds[n]] = pp[n];
+            if (st == 0 && do_ref) fetch(k, 1);
+            else if (k + 1 < m.Na) fetch(k + 1, 0);
             __syncthreads();
             // H stage (along columns): items (cb, r), r fastest: 4 x Q <= 256
             if (tid < 4 * C::Q) {
