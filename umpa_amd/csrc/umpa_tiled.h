@@ -499,8 +499,9 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // three-frame ring 1.94-2.04.  Per workgroup and pass (s_memtime, 32x32 / 256 / 2 per CU): frame loop 37 k cycles,
 // flush 21 k (planes to LDS 3.5 k, column filter 5.2 k, write back 2.5 k, row filter + stores 9.6 k): every shape ends
 // near 30 k CU cycles per 1024 pixels and 9 planes.  C3 on 24-column tiles / 256 threads / 2 per CU: 39.2-39.9
-// against 38.2 on the same box.  Only the winners are instantiated.
-#define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 3) X(2, 16, 256, 1, 2, 1) X(3, 32, 512, 1, 1, 1)
+// against 38.2 on the same box; the 512-thread shape with two flush rounds 39.6 against 40.6 with one (three: 41.8);
+// 32x32 / 256 with five or nine flush rounds 1.88-1.91 against 1.85 with three.  Only the winners are instantiated.
+#define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 3) X(2, 16, 256, 1, 2, 1) X(3, 32, 512, 1, 1, 2)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
 {
@@ -511,25 +512,25 @@ inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, cons
     }
     UMPA_CORR_SHAPES(UMPA_TRY_SHAPE)
 #undef UMPA_TRY_SHAPE
-    return launch_corr<NW, UB, 32, 512, 1, 1, 1>(dev, A, sep, s, fma);
+    return launch_corr<NW, UB, 32, 512, 1, 1, 2>(dev, A, sep, s, fma);
 }
 
 template <int NW>
 inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
 {
     if (ub == 9) {
-        if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s, fma);
+        if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s, fma);
         ub = 8;
     }
     if (ub == 8) {
-        if constexpr (CorrCfg<NW, 8, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 8>(dev, A, sep, s, fma);
+        if constexpr (CorrCfg<NW, 8, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 8>(dev, A, sep, s, fma);
         ub = 7;
     }
     if (ub == 7) {
-        if constexpr (CorrCfg<NW, 7, 32, 512, 1, 1, 1>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s, fma);
+        if constexpr (CorrCfg<NW, 7, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s, fma);
         ub = 5;
     }
-    static_assert(CorrCfg<NW, 5, 32, 512, 1, 1, 1>::OK, "UB=5 must always fit");
+    static_assert(CorrCfg<NW, 5, 32, 512, 1, 1, 2>::OK, "UB=5 must always fit");
     return launch_corr_shape<NW, 5>(dev, A, sep, s, fma);
 }
 
