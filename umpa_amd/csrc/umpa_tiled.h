@@ -379,6 +379,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
 struct TiledState {
     double* maps = nullptr;   size_t maps_cap = 0;
     double* table = nullptr;  size_t table_cap = 0;
+    bool table_limited = false;   // the budget's worth of table could not be allocated once: keep to the capacity we have
     Sep1D sep;
     bool separable = false;
     int sep_nw = -1;
@@ -574,7 +575,7 @@ inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& s
 inline size_t tiled_table_budget()
 {
     const char* e = getenv("UMPA_HIP_TABLE_MB");
-    long mb = e ? atol(e) : 4096;
+    long mb = e ? atol(e) : 16384;                                    // 288 GB of HBM: C3's 30 GB table in two chunks (4 GiB: 50.2 -> 49.3 ms)
     if (mb < 16) mb = 16;
     return (size_t)mb << 20;
 }
@@ -626,11 +627,23 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         if (cap < UMPA_TILE) return (int)hipErrorInvalidValue;
         if (rows_chunk > cap) rows_chunk = cap;
     }
-    const size_t table_need = (size_t)UJ * UJ * rows_chunk * N1d;
+    if (st.table_limited && st.table_cap > 0) {                        // an earlier allocation of the full budget failed: live with what we got
+        const long fit = (long)(st.table_cap / ((size_t)UJ * UJ * N1d)) / UMPA_TILE * UMPA_TILE;
+        if (fit >= UMPA_TILE && fit < rows_chunk) rows_chunk = fit;
+    }
+    size_t table_need = (size_t)UJ * UJ * rows_chunk * N1d;
     if (st.table_cap < table_need) {
         if (st.table) (void)hipFree(st.table);
         st.table = nullptr; st.table_cap = 0;
-        if (hipMalloc((void**)&st.table, table_need * sizeof(double)) != hipSuccess) return -3;
+        // a card with less free memory than the budget assumes: smaller row chunks rather than no tiled path
+        while (hipMalloc((void**)&st.table, table_need * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            st.table = nullptr;
+            if (rows_chunk <= UMPA_TILE) return -3;
+            st.table_limited = true;
+            rows_chunk = std::max<long>(UMPA_TILE, rows_chunk / 2 / UMPA_TILE * UMPA_TILE);
+            table_need = (size_t)UJ * UJ * rows_chunk * N1d;
+        }
         st.table_cap = table_need;
     }
 
