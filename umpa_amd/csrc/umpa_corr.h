@@ -62,6 +62,11 @@ struct CorrArgs {
 };
 
 #define UMPA_LDS_AS __attribute__((address_space(3)))
+// 1: on two-slot rings the next frame is issued right after the products (see the frame loop); 2: on every ring
+// (measured: deeper rings lose the DMA/FMA interleave and pay the second barrier, C3 37.1 -> 42-44 ms)
+#ifndef UMPA_CORR_EARLY_ISSUE
+#define UMPA_CORR_EARLY_ISSUE 1
+#endif
 
 // Tile = TR x TC output pixels (TR = 32 rows).  A workgroup is UI groups of NTG threads: group g works on row
 // offset oi0 + g, all groups share the staged frames (the A image, and a B image of QR + UI - 1 rows), so a pass
@@ -262,7 +267,45 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
             for (int n = 0; n < C::NPT; n++) issue_piece(n);
         }
     };
-    {
+    if constexpr (UMPA_CORR_EARLY_ISSUE >= (C::NSLOT == 2 ? 1 : 2)) {
+        // Frame k+NSLOT goes into the slot of frame k as soon as everyone has multiplied frame k -- a second barrier per
+        // frame, but its DMA then runs beside those of the frames before it instead of starting only when frame k+1 has
+        // landed (NSLOT frames in flight out of NSLOT slots; with the issue at the head of the step, NSLOT-1).
+        if (dma) {
+#pragma unroll
+            for (int f = D; f < C::NSLOT; f++)
+                if (f < K) issue_frame(f);                            // frames 0 .. D-1 went out above
+        }
+        auto products = [&](int k) {
+            if (!prod) return;
+            const pair_t* img = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT);
+            const pair_t* la = img + pr * C::PA + pqb * (C::QB / 2);
+            const pair_t* lb = img + C::QR * C::PA + (pr + grp) * C::PB + pqb * (C::QB / 2);
+            pair_t av[C::QB / 2], bv[C::NBP];
+#pragma unroll
+            for (int t = 0; t < C::QB / 2; t++) av[t] = la[t];
+#pragma unroll
+            for (int t = 0; t < C::NBP; t++) bv[t] = lb[t];
+#pragma unroll
+            for (int t = 0; t < C::QB; t++)
+#pragma unroll
+                for (int u = 0; u < UB; u++) acc[t][u] = fma(av[t >> 1][t & 1], bv[(t + u) >> 1][(t + u) & 1], acc[t][u]);
+        };
+        for (int k = 0; k < K; k++) {
+            // frames k+1 .. min(k+NSLOT-1, K-1) may still be on their way
+            const int behind = dma ? min(C::NSLOT - 1, K - 1 - k) : 0;
+            if (behind >= 3 && C::NSLOT >= 4) wait_vmcnt<3 * C::NPT>();
+            else if (behind == 2 && C::NSLOT >= 3) wait_vmcnt<2 * C::NPT>();
+            else if (behind == 1) wait_vmcnt<C::NPT>();
+            else wait_vmcnt<0>();
+            lds_barrier();
+            products(k);
+            if (k + C::NSLOT < K && dma) {
+                lds_barrier();                                        // slot k % NSLOT has been read by everyone
+                issue_frame(k + C::NSLOT);
+            }
+        }
+    } else {
         int k = 0;
         if (dma) for (; k + D < K; k++) frame_step(k, std::true_type{}, std::false_type{});
         // the last D frames (all frames without DMA): nothing left to issue; once fewer than D frames are outstanding
