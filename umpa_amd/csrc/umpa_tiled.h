@@ -492,9 +492,9 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // Workgroup shapes, first that fits (UMPA_HIP_CORR_SHAPE picks one by number):
 //   id: tile columns, threads per group, groups (row offsets per pass), workgroups per CU, flush rounds.
 // Measured on C2 (ms per corr_volume, round 2; the card's clock state moves all of them by +-5 %):
-//   32x32 tiles / 256 threads (8-wide register blocks) / 2 per CU / three flush rounds, two-slot ring with the next
-//   frame issued right after the products: 1.5-1.65 (the default for windows up to 11); the same with the issue at the
-//   head of the step 1.81-1.91; two flush rounds 1.93, five or nine 1.88-1.91;
+//   32x32 tiles / 256 threads (8-wide register blocks) / 2 per CU / two flush rounds, two-slot ring with the next
+//   frame issued right after the products: 1.5-1.6 (the default for windows up to 11; three flush rounds +2 %, five
+//   +7 %); with the issue at the head of the step 1.81-1.91 (three rounds; two 1.93, five or nine 1.88-1.91);
 //   32x16 tiles / 256 threads / 2 per CU (four-slot ring) 1.95-2.18; 3 per CU with two flush rounds 2.05-2.18;
 //   32x32 with 320 or 384 threads at 2 per CU 2.99-3.46 (168-register cap, spills); two or three row offsets per pass
 //   sharing one staging (512 / 768 threads, one workgroup per CU) 2.16-2.33 / 3.5-4.6; 24-column tiles with a three-frame
@@ -505,7 +505,7 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // 42-44; 384 threads 46.1-51.6.
 // Per workgroup and pass (s_memtime, 32x32 / 256 / 2 per CU, issue at the head): frame loop 37 k cycles, flush 21 k
 // (planes to LDS 3.5 k, column filter 5.2 k, write back 2.5 k, row filter + stores 9.6 k).
-#define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 3) X(2, 24, 256, 1, 2, 2) X(3, 16, 256, 1, 2, 1) X(4, 32, 512, 1, 1, 2)
+#define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 2) X(2, 24, 256, 1, 2, 2) X(3, 16, 256, 1, 2, 1) X(4, 32, 512, 1, 1, 2)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
 {
