@@ -4,6 +4,8 @@ sizes, search ranges, both models, both coordinate conventions, the three sub-pi
 shifts, masks, and both kernel paths.  Same bar as everywhere (conftest.assert_parity): err / Ncalls /
 integer minimum bit-exact, float maps <= 1e-5.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -39,7 +41,8 @@ def _configs(n, seed):
     return out
 
 
-CONFIGS = _configs(60, 20261003)
+# UMPA_FUZZ_N / UMPA_FUZZ_SEED: a longer or different sweep for soak runs (the committed default is what the suite runs)
+CONFIGS = _configs(int(os.environ.get("UMPA_FUZZ_N", "60")), int(os.environ.get("UMPA_FUZZ_SEED", "20261003")))
 
 
 @pytest.mark.parametrize("c", CONFIGS, ids=["%02d" % q for q in range(len(CONFIGS))])
