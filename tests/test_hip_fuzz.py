@@ -23,6 +23,9 @@ def namespaces():
     return model, cpu_model.port
 
 
+SCALE = int(os.environ.get("UMPA_FUZZ_SCALE", "1"))       # soak runs: larger images (several tiles and passes per launch)
+
+
 def _configs(n, seed):
     rng = np.random.default_rng(seed)
     out = []
@@ -31,7 +34,7 @@ def _configs(n, seed):
         ms = int(rng.integers(1, 8))
         P = Nw + ms
         c = dict(Nw=Nw, ms=ms, K=int(rng.choice([1, 2, 3, 5, 7, 10, 13, 16, 17, 20, 24, 25, 29])),
-                 H=2 * P + int(rng.integers(8, 90)), W=2 * P + int(rng.integers(8, 110)),
+                 H=2 * P + SCALE * int(rng.integers(8, 90)), W=2 * P + SCALE * int(rng.integers(8, 110)),
                  df=bool(rng.integers(0, 2)), assign=str(rng.choice(["sam", "ref"])),
                  subpx=int(rng.choice([-1, -1, 0, 1])), step=int(rng.choice([1, 1, 1, 2, 3])),
                  dxdy=None if rng.random() < 0.7 else (int(rng.integers(-1, 2)), int(rng.integers(-1, 2))),
