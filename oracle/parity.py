@@ -42,7 +42,8 @@ def assert_parity(got, want, max_shift, label="", allow_illposed=None, subpx=-1,
             reference's own Newton iteration is not converged there (`newton_unconverged`: the
             iteration stops at a step of 1e-4 px or after 21 steps, Optim.cpp:91,123, so where it
             converges slowly the answer depends on rounding -- two builds of the reference itself
-            differ on such pixels, SURVEY.md section 7); those pixels are counted and bounded;
+            differ on such pixels), or where its trajectory does not survive rounding
+            noise of the 4x4 inputs (`newton_unstable`); those pixels are counted and bounded;
       (iv)  err == 0 pixels: dx, dy bit-exact; T, df, f <= 1e-5 relative.  `f` is excluded where the walk
             failed before its first move: the reference then returns an uninitialised stack variable
             (`T D;` in Model.cpp:566/:927 is only assigned at Optim.cpp:423 or :399-404); this repo's
@@ -79,7 +80,13 @@ def assert_parity(got, want, max_shift, label="", allow_illposed=None, subpx=-1,
         assert "debug_a" in got and "debug_d" in got, \
             "%s: %d in-box ok pixels miss the 1e-5 bar (no debug arrays to classify them)" % (label, miss.sum())
         for (xi, xj) in np.argwhere(miss):
-            if not newton_unconverged(got["debug_a"][xi, xj], got["debug_d"][xi, xj]):
+            illposed = newton_unconverged(got["debug_a"][xi, xj], got["debug_d"][xi, xj])
+            if not illposed and "debug_a" in want and "debug_d" in want:
+                # the reference's own neighbourhood (it differs from ours in the last bits): unconverged there, or a
+                # Newton trajectory that does not survive rounding noise (newton_unstable)
+                illposed = (newton_unconverged(want["debug_a"][xi, xj], want["debug_d"][xi, xj]) or
+                            newton_unstable(want["debug_a"][xi, xj], want["debug_d"][xi, xj]))
+            if not illposed:
                 raise AssertionError("%s: pixel (%d,%d) misses the 1e-5 bar although the reference's Newton "
                                      "iteration is converged there: dx %r vs %r, dy %r vs %r, f %r vs %r" % (
                                          label, xi, xj, got["dx"][xi, xj], want["dx"][xi, xj], got["dy"][xi, xj],
@@ -97,6 +104,35 @@ def assert_parity(got, want, max_shift, label="", allow_illposed=None, subpx=-1,
         assert not np.any(r[sel] > RTOL), "%s f: max rel %.3e on failed pixels" % (label, r[sel].max())
     OBSERVED.append((label, int(ok.sum()), int(inside.sum()), int(unconverged)))
     return dict(ok=int(ok.sum()), inside=int(inside.sum()), unconverged=int(unconverged))
+
+
+def _spmin_from_start(a16, memo25):
+    import ctypes as C
+    from oracle import cpu_model
+    lib = cpu_model.native("port")
+    dp = C.POINTER(C.c_double)
+    a = np.ascontiguousarray(a16, dtype=np.float64)
+    ip = 1 if memo25[17] < memo25[7] else 0          # Optim.cpp:344-345
+    jp = 1 if memo25[13] < memo25[11] else 0
+    p = np.array([1.0 - ip, 1.0 - jp])
+    lib.spmin(a.ctypes.data_as(dp), p.ctypes.data_as(dp))
+    return p
+
+
+def newton_unstable(a16, memo25, eps=1e-14):
+    """True where the reference's spmin is not reproducible on this 4x4 neighbourhood at the level of rounding noise:
+    scaling single entries by (1 +- 1e-14) -- what a different summation order or a -ffast-math build does to them --
+    moves its answer by more than 1e-6 px.  Seen where the unclamped Newton iteration (Optim.cpp:91-124: no damping,
+    no determinant check) bounces between saddle regions for most of its 21 steps before it settles or runs out:
+    which step is the last one then depends on the last bits of the input."""
+    a = np.ascontiguousarray(a16, dtype=np.float64)
+    p0 = _spmin_from_start(a, memo25)
+    rng = np.random.default_rng(12345)               # fixed patterns: the verdict on a pixel is reproducible
+    for _ in range(8):
+        p = _spmin_from_start(a * (1.0 + eps * rng.choice([-1.0, 1.0], size=a.shape)), memo25)
+        if np.any(~(np.abs(p - p0) <= 1e-6 * np.maximum(1.0, np.abs(p0)))):
+            return True
+    return False
 
 
 def newton_unconverged(a16, memo25):
