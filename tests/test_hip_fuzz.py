@@ -71,3 +71,43 @@ def test_random_configuration(namespaces, c):
         kw["dxdy"] = c["dxdy"]
     got, want = g.match(**kw), o.match(**kw)
     assert_parity(got, want, c["ms"], str(c), subpx=c["subpx"])
+
+
+def _stepping_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for q in range(n):
+        Nw = int(rng.integers(1, 7))
+        ms = int(rng.integers(2, 6))
+        P = Nw + ms
+        K = int(rng.integers(2, 6))
+        span = int(rng.integers(0, 16))
+        pos = rng.integers(0, span + 1, size=(K, 2))
+        pos -= pos.min(axis=0)                              # per-axis minimum 0 (model.pyx:274-279)
+        out.append(dict(Nw=Nw, ms=ms, K=K, pos=[tuple(int(v) for v in p) for p in pos],
+                        H=2 * P + SCALE * int(rng.integers(20, 110)), W=2 * P + SCALE * int(rng.integers(20, 130)),
+                        df=bool(rng.integers(0, 2)), assign=str(rng.choice(["sam", "ref"])),
+                        step=int(rng.choice([1, 1, 2])), amp=float(rng.uniform(0.2, max(0.3, ms - 1.2))), seed=5000 + q))
+    return out
+
+
+STEPPING = _stepping_configs(int(os.environ.get("UMPA_FUZZ_N", "24")) // 2 + 12, int(os.environ.get("UMPA_FUZZ_SEED", "20261004")) + 1)
+
+
+@pytest.mark.parametrize("c", STEPPING, ids=["s%02d" % q for q in range(len(STEPPING))])
+def test_random_sample_stepping(namespaces, c):
+    """Frames of one shape at random positions: the fully covered rectangle on the tiled path, the border strips on
+    the general kernels (or everything on them when there is no such rectangle), coverage map included."""
+    from umpa_amd.synth import make_stack
+    hip_ns, port_ns = namespaces
+    frames = [make_stack(c["H"], c["W"], 1, c["ms"], df=c["df"], seed=c["seed"] + 17 * k, amplitude=c["amp"], order=1)
+              for k in range(c["K"])]
+    sam = [np.ascontiguousarray(f[0][0]) for f in frames]
+    ref = [np.ascontiguousarray(f[1][0]) for f in frames]
+    name = "UMPAModelDF" if c["df"] else "UMPAModelNoDF"
+    kw = dict(window_size=c["Nw"], max_shift=c["ms"], pos_list=[np.array(p) for p in c["pos"]])
+    g, o = getattr(hip_ns, name)(sam, ref, **kw), getattr(port_ns, name)(sam, ref, **kw)
+    g.assign_coordinates = o.assign_coordinates = c["assign"]
+    got, want = g.match(step=c["step"], quiet=True), o.match(step=c["step"], quiet=True)
+    assert_parity(got, want, c["ms"], "stepping " + str(c))
+    np.testing.assert_array_equal(g.coverage(), o.coverage())
