@@ -8,14 +8,17 @@
 //
 // Staging is LDS-DMA (global_load_lds_dwordx4): the frames go from L2 straight into LDS, no VGPRs, no
 // ds_write.  A wave-instruction writes 64 consecutive 16-byte pieces, the SOURCE address is per lane, so
-// the LDS image is a plain row-major patch [row][column pair] filled in piece order; a ring of NSLOT
-// frame slots keeps NSLOT-1 frames in flight behind the one being multiplied (one raw s_barrier per
-// frame, counted s_waitcnt vmcnt).  Product threads own one patch row and QB consecutive columns and
-// read them as column pairs (ds_read_b128): with an odd number of pieces per image row the 16 lanes of
-// a b128 group (consecutive rows) hit 16 different 16-byte slots -- conflict free.
+// the LDS image is a plain row-major patch [row][column pair] filled in piece order, in a ring of NSLOT
+// frame slots with counted s_waitcnt vmcnt (no drain in the loop).  Two-slot rings (the 2-workgroups-per-CU
+// shapes): frame k+2 is issued into the slot of frame k as soon as everyone has multiplied frame k, so two
+// frames travel at a time; deeper rings: frame k+NSLOT-1 is issued at the head of step k, its DMA
+// instructions spread between the product rows.  Product threads own one patch row and QB consecutive
+// columns and read them as column pairs (ds_read_b128): with an odd number of pieces per image row the 16
+// lanes of a b128 group (consecutive rows) hit 16 different 16-byte slots -- conflict free.
 //
-// After the last frame the UB product planes go to LDS (transposed, [column][row], odd pitch), get the
-// window's column filter in place and its row filter on the way to the table, as before.
+// After the last frame the product planes go to LDS in NF rounds (transposed, [column][row], odd row pitch,
+// plane pitch = QR mod 32), get the window's column filter in place and its row filter -- one column per
+// lane, adjacent lanes swapping rows by DPP -- on the way to the table (16-byte non-temporal stores).
 #pragma once
 #include "umpa_direct.h"
 #include <type_traits>
