@@ -497,8 +497,8 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 //   +7 %); with the issue at the head of the step 1.81-1.91 (three rounds; two 1.93, five or nine 1.88-1.91);
 //   32x16 tiles / 256 threads / 2 per CU (four-slot ring) 1.95-2.18; 3 per CU with two flush rounds 2.05-2.18;
 //   32x32 with 320 or 384 threads at 2 per CU 2.99-3.46 (168-register cap, spills); two or three row offsets per pass
-//   sharing one staging (512 / 768 threads, one workgroup per CU) 2.16-2.33 / 3.5-4.6; 24-column tiles with a three-frame
-//   ring 1.94-2.04.
+//   sharing one staging (512 / 768 threads, one workgroup per CU) 1.68 / 3.5-4.6 (2.16-2.33 before the non-temporal
+//   stores and the flush re-layout); 24-column tiles with a three-frame ring 1.94-2.04.
 // C3 (window 15; 32x32 / 256 does not hold the halo rows): 24-column tiles / 256 threads / 2 per CU / two flush rounds,
 // two-slot ring with the early issue 36.0; 32x32 / 512 threads / 1 per CU (four-slot ring, DMA instructions between the
 // product rows) 37.0-38.2 with two flush rounds, 38.2-40.6 with one, 41.8 with three; the early issue on that ring
