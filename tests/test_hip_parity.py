@@ -416,3 +416,61 @@ def _with_nw(hip_ns, sam, ref, nw):
     m = hip_ns.UMPAModelDF(sam, ref, window_size=3, max_shift=4)
     m.Nw = nw
     return m.match(quiet=True)
+
+
+@pytest.mark.parametrize("name", ["C_mask", "C_mask_ones"])
+def test_masked_goldens_on_the_tiled_path(hip_ns, name):
+    """Models with masks run on the tiled path (corr_masked + replay_cost, umpa_masked.h): the goldens frozen from the
+    reference, with the path forced so that a silent fall-back to the general kernel fails."""
+    from umpa_amd import _lib
+    case = Case(name)
+    for n, v in enumerate(case.variants):
+        cls = getattr(hip_ns, v["model"])
+        orig = cls._force
+        try:
+            cls._force = _lib.F_FORCE_TILED
+            got, m = case.run(hip_ns, n)
+        finally:
+            cls._force = orig
+        assert m._lib.last_path(m._handle) == 2
+        assert_parity(got, case.expected(n), case.max_shift, "%s v%d" % (name, n), subpx=v.get("subpx", -1))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(H=150, W=170, K=4, Nw=5, ms=5, df=True, amp=2.5, kind="binary"),
+    dict(H=150, W=170, K=4, Nw=5, ms=5, df=False, amp=2.5, kind="binary"),
+    dict(H=120, W=131, K=3, Nw=3, ms=4, df=True, amp=2.0, kind="weights"),     # real-valued weights, odd output width
+    dict(H=120, W=131, K=3, Nw=3, ms=4, df=False, amp=2.0, kind="weights"),
+    dict(H=90, W=100, K=6, Nw=1, ms=3, df=True, amp=1.0, kind="binary"),       # 3x3 windows: enough frames to keep the fits well-posed
+    dict(H=100, W=90, K=5, Nw=2, ms=2, df=False, amp=0.5, kind="binary"),
+    dict(H=110, W=120, K=3, Nw=4, ms=6, df=True, amp=3.0, kind="blocks"),      # whole regions masked out: coverage threshold
+    dict(H=130, W=140, K=2, Nw=6, ms=3, df=True, amp=1.0, kind="weights"),
+    dict(H=140, W=150, K=3, Nw=7, ms=4, df=True, amp=2.0, kind="binary"),      # two column offsets per pass
+    dict(H=140, W=150, K=2, Nw=8, ms=3, df=False, amp=1.0, kind="weights"),
+    dict(H=100, W=100, K=11, Nw=2, ms=4, df=True, amp=2.0, kind="binary"),     # odd frame count: the frame-pair layout of the means
+])
+def test_masked_models_against_the_oracle(hip_ns, port_ns, cfg):
+    """corr_masked / replay_cost against the CPU oracle: binary masks, real-valued weights, masked-out blocks, both
+    models, both coordinate conventions, steps and start shifts; every window half-width the kernel is built for."""
+    from umpa_amd import _lib
+    from umpa_amd.synth import make_stack
+    sam, ref, _ = make_stack(cfg["H"], cfg["W"], cfg["K"], cfg["ms"], df=cfg["df"], seed=77, amplitude=cfg["amp"], order=1)
+    rng = np.random.default_rng(5)
+    if cfg["kind"] == "binary":
+        mask = (rng.random(sam.shape) < 0.9).astype(np.float64)
+    elif cfg["kind"] == "weights":
+        mask = rng.uniform(0.0, 1.0, size=sam.shape) * (rng.random(sam.shape) < 0.95)
+    else:
+        mask = np.ones(sam.shape)
+        mask[:, 30:60, 40:80] = 0.0
+        mask[0, :, :20] = 0.0
+    name = "UMPAModelDF" if cfg["df"] else "UMPAModelNoDF"
+    for assign, mk in (("sam", dict()), ("ref", dict(step=2, dxdy=(1, -1)))):
+        g = getattr(hip_ns, name)(sam, ref, mask_list=mask, window_size=cfg["Nw"], max_shift=cfg["ms"])
+        o = getattr(port_ns, name)(sam, ref, mask_list=mask, window_size=cfg["Nw"], max_shift=cfg["ms"])
+        g.assign_coordinates = o.assign_coordinates = assign
+        g._force = _lib.F_FORCE_TILED
+        got, want = g.match(quiet=True, **mk), o.match(quiet=True, **mk)
+        assert g._lib.last_path(g._handle) == 2
+        st = assert_parity(got, want, cfg["ms"], "masked %s %s %s" % (name, assign, cfg))
+        assert st["ok"] > 0

@@ -113,8 +113,8 @@ struct umpa_hip_model {
 
 namespace {
 
-const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk", "match_staged"};
-enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4, KN_STAGED = 5 };
+const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk", "match_staged", "corr_masked", "replay_cost"};
+enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4, KN_STAGED = 5, KN_MASKED = 6, KN_REPLAY_COST = 7 };
 
 hipEvent_t get_event(umpa_hip_model* m)
 {
@@ -332,9 +332,12 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
 // dealt with by run_match)
 bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
 {
-    if (m->has_mask || m->kind == UMPA_HIP_KIND_DFKERNEL) return false;
+    if (m->kind == UMPA_HIP_KIND_DFKERNEL) return false;
+    if (m->has_mask && !masked_supported(m->Nw)) return false;        // corr_masked + replay_cost (umpa_masked.h)
     for (int k = 0; k < m->Na; k++)
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
+    // corr_volume / corr_masked address a frame with 32-bit byte offsets (LDS-DMA source = base + per-lane offset)
+    if ((size_t)m->dims[0] * m->dims[1] * sizeof(double) >= ((size_t)1 << 32)) return false;
     // stepped regions: the tiled kernels still compute the dense grid, which pays while step0*step1 is small
     // (the direct kernel's cost is per requested pixel, about 20x the tiled cost per dense pixel)
     if (A.step0 * A.step1 > 9) return false;
@@ -384,8 +387,11 @@ int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int fla
 {
     TiledTimers tt;
     tt.get = [m]() { return get_event(m); };
-    int rc = tiled_match(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
-                         m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
+    int rc = m->has_mask
+        ? tiled_match_masked(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
+                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows)
+        : tiled_match(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
+                      m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
     if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
     if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
     for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; m->launches.push_back(tl); }

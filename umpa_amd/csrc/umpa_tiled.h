@@ -27,6 +27,7 @@
 #pragma once
 #include "umpa_direct.h"
 #include "umpa_corr.h"
+#include "umpa_masked.h"
 #include <mutex>
 #include <vector>
 #include <functional>
@@ -718,6 +719,177 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         } else if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1, 0>), grd, blk, 0, s, dev, M, R, A);
         else hipLaunchKernelGGL((replay_walk_kernel<0, 0>), grd, blk, 0, s, dev, M, R, A);
 #undef UMPA_REPLAY_NA
+        toc();
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        if (on_rows) on_rows(xi_lo, xi_hi);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// models with masks: corr_masked + replay_cost (umpa_masked.h)
+// ------------------------------------------------------------------------------------------------
+// column offsets per pass: as many as the registers hold accumulated planes for (DF also keeps the filter threads' sums)
+template <int KIND, int NW>
+constexpr int masked_ub() { return KIND == 1 ? (NW <= 6 ? 3 : 2) : (NW <= 6 ? 5 : 3); }
+
+template <int NW>
+constexpr bool masked_cfg_ok() { return MaskCfg<0, NW, masked_ub<0, NW>()>::OK && MaskCfg<1, NW, masked_ub<1, NW>()>::OK; }
+
+inline bool masked_supported(int Nw)
+{
+    bool ok = false;
+    UMPA_NW_SWITCH(Nw, (ok = masked_cfg_ok<NWC>()))
+    return ok;
+}
+
+template <int KIND, int NW>
+inline hipError_t launch_masked(const ModelDev& dev, MaskedArgs A, const Sep1D& sep, hipStream_t s, double* fma)
+{
+    constexpr int UBM = masked_ub<KIND, NW>();
+    using C = MaskCfg<KIND, NW, UBM>;
+    if constexpr (!C::OK) return hipErrorInvalidValue;
+    else {
+        static bool attr_set[64] = {};
+        int devid = 0;
+        (void)hipGetDevice(&devid);
+        {
+            std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+            if (!attr_set[devid & 63]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_masked_kernel<KIND, NW, UBM>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+                if (e != hipSuccess) return e;
+                attr_set[devid & 63] = true;
+            }
+        }
+        A.ntx = (A.N1 + C::TC - 1) / C::TC;
+        A.nty = (A.rows + C::TR - 1) / C::TR;
+        const int UJ = 2 * dev.ms - 1, nbatch = (UJ + UBM - 1) / UBM, npass = UJ * nbatch;
+        const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
+        const int grid = 8 * tiles_per_xcd * npass;
+        if (fma) {
+            // fp64 issue slots (FMA, multiply or add each counted once) this launch executes, per (tile, row offset):
+            // per frame and real column offset the products of the active threads (pair weight 6 + 7) and, DF, three
+            // planes through both filters + the fold into t2, t4, t6; at the end NPL (+1) planes through both filters
+            const double filt = (double)C::QR * C::TC * C::S + (double)C::TR * C::TC * C::S;
+            const double prod = (double)C::QR * C::NQB * C::QB * 13.0;
+            const double per_shift_frame = prod + (KIND == 1 ? 3.0 * filt + 2.0 * C::TR * C::TC * 3.0 : 0.0);
+            const double per_shift_end = (KIND == 1 ? 2.0 : 1.0) * C::NPL * filt + 20.0 * C::TR * C::TC;
+            *fma = (per_shift_frame * dev.Na + per_shift_end) * UJ * UJ * (double)A.ntx * A.nty;
+        }
+        hipLaunchKernelGGL((corr_masked_kernel<KIND, NW, UBM>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
+        return hipGetLastError();
+    }
+}
+
+// One match of a region of a masked model.  Returns 0, -3 (allocation) or a positive hipError_t.
+inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int H, int W, const FrameBox& box, const RegionArgs& A,
+                              hipStream_t s, TiledTimers* tt, bool reuse_ref_maps,
+                              int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
+{
+    const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1, NV = kind == 1 ? 3 : 2;
+    const size_t plane = (size_t)H * W;
+    const size_t KP = ((size_t)K + 1) / 2;
+    Maps M;
+    M.H = H; M.W = W;
+    M.br0 = box.r0; M.br1 = box.r1; M.bc0 = box.c0; M.bc1 = box.c1; M.Wf = box.Wf;
+    M.SamSq = M.RefSq = M.WS = M.MR = nullptr;
+    if (kind == 1) {                                                   // the un-weighted reference means (Model.cpp:804-808): prep_maps' MR planes
+        const size_t nmaps = 2 + 4 * KP;
+        if (st.maps_cap < nmaps * plane) {
+            if (st.maps) (void)hipFree(st.maps);
+            st.maps = nullptr; st.maps_cap = 0;
+            st.ref_maps_ok = false;
+            if (hipMalloc((void**)&st.maps, nmaps * plane * sizeof(double)) != hipSuccess) return -3;
+            st.maps_cap = nmaps * plane;
+        }
+        if (st.ref_kind != kind || st.ref_K != K || st.ref_plane != plane) st.ref_maps_ok = false;
+        M.SamSq = st.maps; M.RefSq = st.maps + plane;
+        M.WS = st.maps + 2 * plane;
+        M.MR = st.maps + (2 + 2 * KP) * plane;
+    }
+    const int N0d = A.step0 * (A.N0 - 1) + 1, N1d = A.step1 * (A.N1 - 1) + 1;
+    const size_t row_bytes = (size_t)NV * UJ * UJ * N1d * sizeof(double);
+    long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
+    if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
+    if (rows_chunk > N0d) rows_chunk = ((long)N0d + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+    if (piece_rows > 0) {
+        const long want = ((long)piece_rows + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
+        if (want < rows_chunk) rows_chunk = want;
+    }
+    if (st.table_limited && st.table_cap > 0) {
+        const long fit = (long)(st.table_cap / ((size_t)NV * UJ * UJ * N1d)) / UMPA_TILE * UMPA_TILE;
+        if (fit >= UMPA_TILE && fit < rows_chunk) rows_chunk = fit;
+    }
+    size_t table_need = (size_t)NV * UJ * UJ * rows_chunk * N1d;
+    if (st.table_cap < table_need) {
+        if (st.table) (void)hipFree(st.table);
+        st.table = nullptr; st.table_cap = 0;
+        while (hipMalloc((void**)&st.table, table_need * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            st.table = nullptr;
+            if (rows_chunk <= UMPA_TILE) return -3;
+            st.table_limited = true;
+            rows_chunk = std::max<long>(UMPA_TILE, rows_chunk / 2 / UMPA_TILE * UMPA_TILE);
+            table_need = (size_t)NV * UJ * UJ * rows_chunk * N1d;
+        }
+        st.table_cap = table_need;
+    }
+
+    bool timing_open = false;
+    auto tic = [&](int name) {
+        timing_open = false;
+        if (!tt) return;
+        TiledTimers::Entry en = {name, tt->get(), tt->get(), 0.0};
+        if (!en.t0 || !en.t1) return;
+        (void)hipEventRecord(en.t0, s);
+        tt->entries.push_back(en);
+        timing_open = true;
+    };
+    auto toc = [&](double fma = 0.0) {
+        if (!timing_open) return;
+        tt->entries.back().fma = fma;
+        (void)hipEventRecord(tt->entries.back().t1, s);
+        timing_open = false;
+    };
+
+    hipError_t e = hipErrorInvalidValue;
+    if (kind == 1) {
+        const int sides = (reuse_ref_maps && st.ref_maps_ok) ? 0 : 3;   // only the reference means are read: nothing to redo for a new sample stack
+        st.ref_maps_ok = false;
+        if (sides) {
+            tic(2);
+            UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, sides, s)))
+            toc();
+            if (e != hipSuccess) return (int)e;
+        }
+        st.ref_maps_ok = true; st.ref_kind = kind; st.ref_K = K; st.ref_plane = plane;
+    }
+    for (int drow0 = 0; drow0 < N0d; drow0 += (int)rows_chunk) {
+        const int drows = (int)((N0d - drow0 < rows_chunk) ? N0d - drow0 : rows_chunk);
+        MaskedArgs MA;
+        MA.table = st.table; MA.slot_stride = (size_t)drows * N1d;
+        MA.MR = M.MR; MA.H = H; MA.W = W;
+        MA.org0 = A.org0; MA.org1 = A.org1; MA.row0 = drow0; MA.rows = drows; MA.N1 = N1d;
+        MA.sigma = dev.ref_mode ? -1 : 1;
+        MA.br0 = box.r0; MA.br1 = box.r1; MA.bc0 = box.c0; MA.bc1 = box.c1; MA.Wf = box.Wf;
+        MA.ntx = MA.nty = 0;
+        { const char* ab = getenv("UMPA_HIP_ABLATE_MASKED"); MA.ablate = ab ? atoi(ab) : 0; }
+        e = hipErrorInvalidValue;
+        double fma = 0.0;
+        tic(6);
+        if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_masked<1, NWC>(dev, MA, st.sep, s, &fma))) }
+        else { UMPA_NW_SWITCH(Nw, (e = launch_masked<0, NWC>(dev, MA, st.sep, s, &fma))) }
+        toc(fma);
+        if (e != hipSuccess) return (int)e;
+        const int xi_lo = (drow0 + A.step0 - 1) / A.step0;
+        const int xi_hi = std::min(A.N0, (drow0 + drows - 1) / A.step0 + 1);
+        if (xi_hi <= xi_lo) continue;
+        dim3 blk(64), grd((A.N1 + 63) / 64, xi_hi - xi_lo);
+        tic(7);
+        if (kind == 1) hipLaunchKernelGGL((replay_cost_kernel<1>), grd, blk, 0, s, dev, (const double*)st.table, MA.slot_stride, drow0, N1d, xi_lo, xi_hi - xi_lo, A);
+        else hipLaunchKernelGGL((replay_cost_kernel<0>), grd, blk, 0, s, dev, (const double*)st.table, MA.slot_stride, drow0, N1d, xi_lo, xi_hi - xi_lo, A);
         toc();
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
