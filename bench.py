@@ -192,6 +192,8 @@ def main():
 
     step(with_ncalls=True)                                  # untimed: evaluation-count statistics of this dataset
     torch.cuda.synchronize()
+    st4 = (ctypes.c_double * 4)()
+    lib.check(lib.last_stats(h, st4), "last_stats")         # on-demand passes of the shift table (umpa_ondemand.h)
     nc = ncalls.cpu().numpy()
     err_h = err.cpu().numpy()
 
@@ -212,6 +214,8 @@ def main():
                    "output_pixels_per_gpu": npx, "kernel_path": path,
                    "Ncalls_mean": round(float(nc.mean()), 3), "Ncalls_p99": int(np.percentile(nc, 99)),
                    "err_ok_fraction": round(float(err_h.mean()), 5), "parallelism": "1 GPU",
+                   "table_passes_computed": int(st4[0]), "table_passes_exhaustive": int(st4[1]),
+                   "pixels_replayed_twice": int(st4[2]), "tiles_repaired": int(st4[3]),
                    "input_generation_s": round(t_gen, 1)},
         "roofline": roof,
         "cpu_baseline": cpu,

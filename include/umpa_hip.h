@@ -192,6 +192,10 @@ int umpa_hip_timing_fma(umpa_hip_model *m, int index, double *fma);
 /* which path the last match_region took: 0 none, 1 direct (plain), 2 tiled, 3 direct (staged: windows out of LDS),
  * 4 sample stepping: tiled on the rectangle every frame contributes to + general kernels on the border strips */
 int umpa_hip_last_path(umpa_hip_model *m);
+/* the tiled path computes only the passes of its shift table that walks read (seed tiles predict, misses are repaired:
+ * the maps are those of the exhaustive table): out4 = { (tile, pass) units computed by the last match, units of the
+ * exhaustive table, pixels whose walk had to be run again, tiles whose prediction fell short }.  Waits for the device. */
+int umpa_hip_last_stats(umpa_hip_model *m, double *out4);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ HIP_SYMBOLS = [
     "device_count", "last_error", "version", "create", "destroy", "set_window", "set_subpx",
     "set_reference_shift", "coverage", "coverage_region", "cost", "min", "match_region",
     "spmin", "spmin_quad", "timing_enable", "timing_collect", "timing_read", "timing_fma", "last_path", "host_alloc", "host_free", "host_trim", "stage_sample", "wait", "set_rows_callback", "host_register", "host_unregister",
-    "update_frames", "correct_bad_pixels",
+    "update_frames", "correct_bad_pixels", "last_stats",
 ]
 
 
@@ -85,6 +85,7 @@ class Native:
             f("host_register", C.c_int, [C.c_void_p, C.c_size_t])
             f("host_unregister", C.c_int, [C.c_void_p])
             f("last_path", C.c_int, [C.c_void_p])
+            f("last_stats", C.c_int, [C.c_void_p, _dp])
             f("update_frames", C.c_int, [C.c_void_p, _dpp, _dpp])
             f("correct_bad_pixels", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
                                               C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p])

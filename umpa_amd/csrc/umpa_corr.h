@@ -21,6 +21,7 @@
 // lane, adjacent lanes swapping rows by DPP -- on the way to the table (16-byte non-temporal stores).
 #pragma once
 #include "umpa_direct.h"
+#include "umpa_ondemand.h"
 #include <type_traits>
 
 namespace umpa {
@@ -145,28 +146,17 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
+// the planes of one (tile, pass) into the table
 template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
-__global__ void __launch_bounds__(NTG * UI, (NTG * UI / 64 * WPC + 3) / 4)
-corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
+__device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrArgs& A, const Sep1D& sep, double* lds,
+                                                 const int lin, const int pass, const int tid)
 {
     using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>;
     constexpr int NT = C::NT;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* lds = reinterpret_cast<double*>(smem_raw);
-
-    // One workgroup = one (tile, pass): a pass is UI consecutive row offsets and one batch of UB column offsets.
-    // The passes of a tile read the same A patch and overlapping B patches; they get consecutive slots on ONE XCD
-    // (blocks b, b+8, ... share an XCD) so that those re-reads are served by that XCD's L2 instead of crossing the
-    // fabric once per pass.  Placement only affects speed.
     const int ms = m.ms, UJ = 2 * ms - 1;
-    const int nbatch = (UJ + UB - 1) / UB, npass = ((UJ + UI - 1) / UI) * nbatch;
-    const int ntiles = A.ntx * A.nty, tiles_per_xcd = (ntiles + 7) >> 3;
-    const int seq = blockIdx.x >> 3;                                  // position in this XCD's queue
-    const int lin = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;   // contiguous band of tiles per XCD
-    const int pass = seq % npass;
-    if (seq / npass >= tiles_per_xcd || lin >= ntiles) return;
+    const int nbatch = (UJ + UB - 1) / UB;
+  do {
     const int tx = lin % A.ntx, ty = lin / A.ntx;
-    const int tid = threadIdx.x;
     const int grp = UI > 1 ? __builtin_amdgcn_readfirstlane(tid / NTG) : 0, gtid = tid - grp * NTG;
     const int prow0 = A.row0 + ty * C::TR, pcol0 = tx * TC;           // first output pixel of the tile (region coords)
     const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
@@ -318,7 +308,7 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
             else frame_step(k, std::false_type{}, std::true_type{});
         }
     }
-    if (A.ablate & 8) return;
+    if (A.ablate & 8) break;
     // ---- all frames of this pass are in.  Plane P = g*UB + u of the pass; round f puts planes [f*PR, (f+1)*PR) into
     // LDS (transposed, [column][row]), filters them along the columns in place and along the rows on the way out.
     const int nu = min(UB, ms - oj0);                                 // column offsets oj0 .. oj0+nu-1 are real
@@ -403,6 +393,60 @@ corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep)
                 }
             }
         }
+    }
+  } while (0);
+}
+
+// (tile, pass) of a workgroup of a static grid: the passes of a tile on consecutive slots of ONE XCD (blocks b, b+8, ...
+// share an XCD), so that their re-reads of the tile's patches are served by that XCD's L2.  Placement only affects speed.
+// od.mode 0: every pass of every tile; 3: a compact grid over the seed tiles (umpa_ondemand.h).
+__device__ __forceinline__ bool od_static_item(const OdCorr& od, int ntx, int ntiles, int npass, int& lin, int& pass)
+{
+    const int nt = od.mode == 3 ? od.nseed : ntiles, tiles_per_xcd = (nt + 7) >> 3;
+    const int seq = blockIdx.x >> 3;                                  // position in this XCD's queue
+    const int t = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;     // contiguous band of tiles per XCD
+    pass = seq % npass;
+    if (seq / npass >= tiles_per_xcd || t >= nt) return false;
+    lin = od.mode == 3 ? (od.r0 + (t / od.nsx) * OD_SP) * ntx + od.c0 + (t % od.nsx) * OD_SP : t;
+    return true;
+}
+
+// the planes of this (tile, pass) are on their way to the table: valid for every later kernel
+__device__ __forceinline__ void od_mark_done(const OdCorr& od, int lin, int pass)
+{
+    if (od.mode != 0 && threadIdx.x == 0) { atomicOr(od.done + lin, 1ull << pass); atomicAdd(od.ndone, 1); }
+}
+
+// One workgroup = one (tile, pass): a pass is UI consecutive row offsets and one batch of UB column offsets.
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+__global__ void __launch_bounds__(NTG * UI, (NTG * UI / 64 * WPC + 3) / 4)
+corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep, OdCorr od)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int UJ = 2 * m.ms - 1, npass = ((UJ + UI - 1) / UI) * ((UJ + UB - 1) / UB);
+    int lin, pass;
+    if (!od_static_item(od, A.ntx, A.ntx * A.nty, npass, lin, pass)) return;
+    corr_volume_tile<NW, UB, TC, NTG, UI, WPC, NF>(m, A, sep, reinterpret_cast<double*>(smem_raw), lin, pass, threadIdx.x);
+    od_mark_done(od, lin, pass);
+}
+
+// The same over a work list of (tile, pass) pairs, by a persistent grid (the predicted passes and the repair rounds of
+// umpa_ondemand.h).  The body is a call in a loop: written out inside the loop it needed more registers than there are.
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+__global__ void __launch_bounds__(NTG * UI, (NTG * UI / 64 * WPC + 3) / 4)
+corr_volume_queue_kernel(ModelDev m, CorrArgs A, Sep1D sep, OdCorr od)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int nitems = __builtin_amdgcn_readfirstlane(*gp(od.nitems));           // (wave-uniform: SGPRs)
+    for (int j = 0;; j++) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                                 // (what follows from it is not to be hoisted out of the loop)
+        const int idx = od_item_index(nitems, blockIdx.x, gridDim.x, j);
+        if (idx < 0) break;
+        const int it = __builtin_amdgcn_readfirstlane(gp(od.items)[idx]);
+        if (j) __syncthreads();                                       // the previous item's last LDS reads
+        corr_volume_tile<NW, UB, TC, NTG, UI, WPC, NF>(m, A, sep, reinterpret_cast<double*>(smem_raw), it >> 8, it & 255, tid);
+        od_mark_done(od, it >> 8, it & 255);
     }
 }
 

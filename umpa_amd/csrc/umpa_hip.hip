@@ -58,7 +58,7 @@ struct DevBuf {                       // grow-only device scratch
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct TimedLaunch { int name; hipEvent_t t0, t1; double fma; };
+struct TimedLaunch { int name; hipEvent_t t0, t1; double fma; const int* counts; double fma_per; };
 
 } // namespace
 
@@ -129,7 +129,7 @@ struct ScopedTimer {                   // brackets a launch with events when tim
     ScopedTimer(umpa_hip_model* m_, hipStream_t s_, int name) : m(m_), s(s_), on(m_->timing)
     {
         if (!on) return;
-        tl.name = name; tl.t0 = get_event(m); tl.t1 = get_event(m); tl.fma = 0.0;
+        tl.name = name; tl.t0 = get_event(m); tl.t1 = get_event(m); tl.fma = 0.0; tl.counts = nullptr; tl.fma_per = 0.0;
         if (!tl.t0 || !tl.t1) { on = false; return; }
         (void)hipEventRecord(tl.t0, s);
     }
@@ -394,7 +394,7 @@ int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int fla
                       m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
     if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
     if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
-    for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; m->launches.push_back(tl); }
+    for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; tl.counts = en.counts; tl.fma_per = en.fma_per; m->launches.push_back(tl); }
     return 0;
 }
 
@@ -1123,7 +1123,8 @@ int umpa_hip_timing_collect(umpa_hip_model* m)
             size_t q = 0;
             for (; q < m->tnames.size(); q++) if (m->tnames[q] == nm) break;
             if (q == m->tnames.size()) { m->tnames.push_back(nm); m->tms.push_back(0.0); m->tcount.push_back(0); m->tfma.push_back(0.0); }
-            m->tms[q] += ms; m->tcount[q] += 1; m->tfma[q] += l.fma;
+            // (the event wait above is behind the copy of the chunk's counters in stream order: counts[3] = passes computed)
+            m->tms[q] += ms; m->tcount[q] += 1; m->tfma[q] += l.fma + (l.counts ? l.fma_per * l.counts[3] : 0.0);
         }
         m->event_pool.push_back(l.t0); m->event_pool.push_back(l.t1);
     }
@@ -1148,5 +1149,26 @@ int umpa_hip_timing_fma(umpa_hip_model* m, int index, double* fma)
 }
 
 int umpa_hip_last_path(umpa_hip_model* m) { return m ? m->last_path : 0; }
+
+int umpa_hip_last_stats(umpa_hip_model* m, double* out4)
+{
+    if (!m || !out4) return fail(UMPA_HIP_E_ARG, "null argument");
+    (void)hipSetDevice(m->device);
+    // the counters were copied behind the match's kernels on the match's stream; the caller has synchronised it (or the
+    // match was a host-array call, which synchronises itself): a device-wide wait makes this safe for either
+    HIP_TRY(hipDeviceSynchronize(), UMPA_HIP_E_DEVICE);
+    const TiledState& st = m->tiled;
+    double done = 0.0, parked = 0.0, missed = 0.0;
+    for (int q = 0; q < st.stat_n; q++) {
+        done += st.stat_slots[q][OD_C_DONE];
+        missed += st.stat_slots[q][OD_C_TILES];                          // tiles whose prediction fell short (stage 0)
+        for (int r = 0; r < OD_ROUNDS; r++) parked += st.stat_slots[q][8 * r + OD_C_PX];   // walks started again, all rounds
+    }
+    out4[0] = st.stat_n ? done : st.stat_total_passes;
+    out4[1] = st.stat_total_passes;
+    out4[2] = parked;
+    out4[3] = missed;
+    return 0;
+}
 
 } // extern "C"

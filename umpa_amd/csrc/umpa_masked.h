@@ -110,28 +110,20 @@ __device__ __forceinline__ void fir_stream(const double* __restrict__ in, int st
     }
 }
 
+// the finished costs of one (tile, pass) into the table
 template <int KIND, int NW, int UB>
-__global__ void __launch_bounds__(512, 2)
-corr_masked_kernel(ModelDev m, MaskedArgs A, Sep1D sep)
+__device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const MaskedArgs& A, const Sep1D& sep, double* ring,
+                                                 const int lin, const int pass, const int tid)
 {
     using C = MaskCfg<KIND, NW, UB>;
     constexpr int NT = C::NT, QB = C::QB, TC = C::TC, TR = C::TR, NPX = C::NPX;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* ring = reinterpret_cast<double*>(smem_raw);                 // the frame slot(s)
     double* sums = ring;                                                // after the last frame: [NSUM][NPX]
     double* planes = KIND == 1 ? ring + C::RING : ring + C::NSUM * NPX;  // NoDF: over the slots, after the last frame
     double* mubuf = ring + C::LDS_DF_NOMU;                              // DF with MULDS: 2 x MU_DMA
-
-    // (tile, pass) of this workgroup: the passes of a tile on consecutive slots of one XCD, as corr_volume
     const int ms = m.ms, UJ = 2 * ms - 1;
-    const int nbatch = (UJ + UB - 1) / UB, npass = UJ * nbatch;
-    const int ntiles = A.ntx * A.nty, tiles_per_xcd = (ntiles + 7) >> 3;
-    const int seq = blockIdx.x >> 3;
-    const int lin = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;
-    const int pass = seq % npass;
-    if (seq / npass >= tiles_per_xcd || lin >= ntiles) return;
+    const int nbatch = (UJ + UB - 1) / UB;
+  {
     const int tx = lin % A.ntx, ty = lin / A.ntx;
-    const int tid = threadIdx.x;
     const int prow0 = A.row0 + ty * TR, pcol0 = tx * TC;
     const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;
     const int oi0 = pass / nbatch - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
@@ -405,6 +397,39 @@ corr_masked_kernel(ModelDev m, MaskedArgs A, Sep1D sep)
             }
         }
     }
+  }
+}
+
+// one workgroup = one (tile, pass) of a static grid (od_static_item, umpa_corr.h)
+template <int KIND, int NW, int UB>
+__global__ void __launch_bounds__(512, 2)
+corr_masked_kernel(ModelDev m, MaskedArgs A, Sep1D sep, OdCorr od)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int UJ = 2 * m.ms - 1, npass = UJ * ((UJ + UB - 1) / UB);
+    int lin, pass;
+    if (!od_static_item(od, A.ntx, A.ntx * A.nty, npass, lin, pass)) return;
+    corr_masked_tile<KIND, NW, UB>(m, A, sep, reinterpret_cast<double*>(smem_raw), lin, pass, threadIdx.x);
+    od_mark_done(od, lin, pass);
+}
+
+// the same over a work list, by a persistent grid (the repair step of umpa_ondemand.h)
+template <int KIND, int NW, int UB>
+__global__ void __launch_bounds__(512, 2)
+corr_masked_queue_kernel(ModelDev m, MaskedArgs A, Sep1D sep, OdCorr od)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int nitems = __builtin_amdgcn_readfirstlane(*gp(od.nitems));
+    for (int j = 0;; j++) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                                   // (what follows from it is not to be hoisted out of the loop)
+        const int idx = od_item_index(nitems, blockIdx.x, gridDim.x, j);
+        if (idx < 0) break;
+        const int it = __builtin_amdgcn_readfirstlane(gp(od.items)[idx]);
+        if (j) __syncthreads();                                         // the previous item's last LDS reads
+        corr_masked_tile<KIND, NW, UB>(m, A, sep, reinterpret_cast<double*>(smem_raw), it >> 8, it & 255, tid);
+        od_mark_done(od, it >> 8, it & 255);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,40 +437,66 @@ corr_masked_kernel(ModelDev m, MaskedArgs A, Sep1D sep)
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ void __launch_bounds__(64, 3)
-replay_cost_kernel(ModelDev m, const double* table, size_t slot_stride, int drow0, int N1d, int row0, int rows, RegionArgs A)
+replay_cost_kernel(ModelDev m, const double* table, size_t slot_stride, int drow0, int N1d, int row0, int rows, RegionArgs A, OdArgs od)
 {
     __shared__ double memo_lds[25 * 64];
     constexpr int NV = KIND == 1 ? 3 : 2;
-    const int xj = blockIdx.x * 64 + threadIdx.x;
-    const int xi = row0 + blockIdx.y;
-    if (xi >= row0 + rows || xj >= A.N1) return;
+    const LdsMemo<64> memo = {memo_lds + threadIdx.x};
+    const int nparked = od.mode == 3 ? __builtin_amdgcn_readfirstlane(gp(od.cnt_in)[OD_C_PX]) : 0;       // od.mode: as replay_walk (umpa_tiled.h)
+  for (int q = (blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x, first = 1;; q += gridDim.x * gridDim.y * 64, first = 0) {
+    int xi, xj;
+    bool live;
+    if (od.mode == 3) {
+        if (__builtin_amdgcn_readfirstlane(q & ~63) >= nparked) break;
+        live = q < nparked;
+        const int pxq = live ? gp(od.px_in)[q] : 0;
+        xi = pxq / A.N1; xj = pxq - xi * A.N1;
+    } else if (od.mode == 1) {
+        if (!first) break;
+        live = od_seed_pixel(od, drow0, A.step0, A.step1, xi, xj);
+        live = live && xi >= row0 && xi < row0 + rows && xj < A.N1;
+    } else {
+        if (!first) break;
+        xj = blockIdx.x * 64 + threadIdx.x;
+        xi = row0 + blockIdx.y;
+        live = xi < row0 + rows && xj < A.N1;
+    }
     const size_t px = (size_t)xi * A.N1 + xj;
     const size_t tpx = (size_t)(xi * A.step0 - drow0) * N1d + (size_t)xj * A.step1;
-    if (A.cover && gp(A.cover)[px] < A.thr) return;
-    const LdsMemo<64> memo = {memo_lds + threadIdx.x};
-    Walk w;
-    walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
-    const int ms = m.ms, UJ = 2 * ms - 1;
-    while (w.phase < PH_FIT) {
-        double c = 0.0;
-        Fit fit = w.live;
-        const int si = w.req_i, sj = w.req_j;
-        int st = UMPA_ST_OK;
-        if (si <= -ms || si >= ms) st = UMPA_ST_BOUND;
-        else if (sj <= -ms) st = UMPA_ST_BOUND | UMPA_ST_DIM;
-        else if (sj >= ms) st = UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
-        else {
-            const size_t slot = (size_t)((si + ms - 1) * UJ + (sj + ms - 1));
-            const UMPA_GLOBAL double* e = gp(table) + slot * NV * slot_stride + tpx;
-            c = e[0];
-            fit.t = e[slot_stride];
-            fit.v = KIND == 1 ? e[2 * slot_stride] : 0.0;
+    if (live && A.cover && gp(A.cover)[px] < A.thr) live = false;
+    OdLane L;
+    if (live && !od_begin(od, xi * A.step0 - drow0, xj * A.step1, L)) live = false;
+    if (live) {
+        Walk w;
+        walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
+        const int ms = m.ms, UJ = 2 * ms - 1, sigma = m.ref_mode ? -1 : 1;
+        while (w.phase < PH_FIT) {
+            double c = 0.0;
+            Fit fit = w.live;
+            const int si = w.req_i, sj = w.req_j;
+            int st = UMPA_ST_OK;
+            if (si <= -ms || si >= ms) st = UMPA_ST_BOUND;
+            else if (sj <= -ms) st = UMPA_ST_BOUND | UMPA_ST_DIM;
+            else if (sj >= ms) st = UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
+            else {
+                if (!od_check(od, L, ms, sigma, si, sj)) break;         // the plane is not there: this pixel is parked
+                const size_t slot = (size_t)((si + ms - 1) * UJ + (sj + ms - 1));
+                const UMPA_GLOBAL double* e = gp(table) + slot * NV * slot_stride + tpx;
+                c = e[0];
+                fit.t = e[slot_stride];
+                fit.v = KIND == 1 ? e[2 * slot_stride] : 0.0;
+            }
+            walk_feed(w, memo, st, c, fit, m.call_cap);
         }
-        walk_feed(w, memo, st, c, fit, m.call_cap);
+        if (L.miss) od_park(od, L, (int)px);
+        else {
+            double nb[16];
+            walk_finish(w, memo, m.subpx, nb);
+            store_pixel(A, px, KIND, w, memo, nb);
+        }
     }
-    double nb[16];
-    walk_finish(w, memo, m.subpx, nb);
-    store_pixel(A, px, KIND, w, memo, nb);
+    if (od.mode == 1) od_record_visited(od, L, live);
+  }
 }
 
 } // namespace umpa

@@ -308,15 +308,39 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
 
 template <int KIND, int NA>
 __global__ void __launch_bounds__(UMPA_REPLAY_THREADS, 3)
-replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
+replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od)
 {
     __shared__ double memo_lds[25 * UMPA_REPLAY_THREADS];
-    const int xj = blockIdx.x * 64 + threadIdx.x;
-    const int xi = R.row0 + blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
-    if (xi >= R.row0 + R.rows || xj >= A.N1) return;
+    const LdsMemo<UMPA_REPLAY_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
+    // od.mode (umpa_ondemand.h): 0 every pixel, every table plane is there; 1 the pixels of the seed tiles (a compact grid;
+    // which passes they read is recorded); 2 the other pixels (a walk that needs a missing pass parks its pixel); 3 a
+    // persistent grid over the parked pixels' list.  No lane leaves before the end: od_record_visited shuffles across the wave.
+    const int nparked = od.mode == 3 ? __builtin_amdgcn_readfirstlane(gp(od.cnt_in)[OD_C_PX]) : 0;
+  for (int q = (blockIdx.y * gridDim.x + blockIdx.x) * UMPA_REPLAY_THREADS + threadIdx.y * 64 + threadIdx.x, first = 1;;
+       q += gridDim.x * gridDim.y * UMPA_REPLAY_THREADS, first = 0) {
+    int xi, xj;
+    bool live;
+    if (od.mode == 3) {
+        if (__builtin_amdgcn_readfirstlane(q & ~63) >= nparked) break;   // whole wave
+        live = q < nparked;
+        const int pxq = live ? gp(od.px_in)[q] : 0;
+        xi = pxq / A.N1; xj = pxq - xi * A.N1;
+    } else if (od.mode == 1) {
+        if (!first) break;
+        live = od_seed_pixel(od, R.drow0, A.step0, A.step1, xi, xj);
+        live = live && xi >= R.row0 && xi < R.row0 + R.rows && xj < A.N1;
+    } else {
+        if (!first) break;
+        xj = blockIdx.x * 64 + threadIdx.x;
+        xi = R.row0 + blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
+        live = xi < R.row0 + R.rows && xj < A.N1;
+    }
     const size_t px = (size_t)xi * A.N1 + xj;
     const size_t tpx = (size_t)(xi * A.step0 - R.drow0) * R.N1d + (size_t)xj * A.step1;
-    if (A.cover && gp(A.cover)[px] < A.thr) return;
+    if (live && A.cover && gp(A.cover)[px] < A.thr) live = false;
+    OdLane L;
+    if (live && !od_begin(od, xi * A.step0 - R.drow0, xj * A.step1, L)) live = false;
+    if (live) {
     const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
     constexpr int NFIX = NA > 0 ? NA : UMPA_KFIX;
     double fixed[NFIX];
@@ -325,10 +349,10 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
         const UMPA_GLOBAL double* __restrict__ fx = gp(m.ref_mode ? M.MR : M.WS);
         if constexpr (NA > 0) {
 #pragma unroll
-            for (int q = 0; q < (NA + 1) / 2; q++) {
-                const map_pair_t v = *reinterpret_cast<const UMPA_GLOBAL map_pair_t*>(fx + ((size_t)q * plane + x0) * 2);
-                fixed[2 * q] = v[0];
-                if (2 * q + 1 < NFIX) fixed[2 * q + 1] = v[1];
+            for (int qq = 0; qq < (NA + 1) / 2; qq++) {
+                const map_pair_t v = *reinterpret_cast<const UMPA_GLOBAL map_pair_t*>(fx + ((size_t)qq * plane + x0) * 2);
+                fixed[2 * qq] = v[0];
+                if (2 * qq + 1 < NFIX) fixed[2 * qq + 1] = v[1];
             }
         } else {
 #pragma unroll
@@ -348,7 +372,6 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
             }
         } else pc.t1 = gp(M.SamSq)[x0];
     }
-    const LdsMemo<UMPA_REPLAY_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);
     if (R.ablate & 1) {                                             // diagnostics: the lookups without the walk
@@ -361,17 +384,25 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A)
         }
         w.out = csum; w.live = fit; w.phase = PH_DONE; w.status = 1;
     }
+    const int sigma = m.ref_mode ? -1 : 1;
     while (w.phase < PH_FIT) {
+        if (!od_check(od, L, m.ms, sigma, w.req_i, w.req_j)) break;  // the plane is not there: this pixel is parked
         double c = 0.0;
         Fit fit = w.live;
         const int st = eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, pc, c, fit);
         walk_feed(w, memo, st, c, fit, m.call_cap);
     }
-    double nb[16];
-    walk_finish(w, memo, (R.ablate & 2) ? 0 : m.subpx, nb);
-    if (KIND == 1 && (w.live.t != 0.0 || w.live.v != 0.0))          // eval_lookup left K in the v slot; (0,0) = never evaluated
-        w.live.v = w.live.v / w.live.t;                             // Model.cpp:854
-    store_pixel(A, px, KIND, w, memo, nb);
+    if (L.miss) od_park(od, L, (int)px);
+    else {
+        double nb[16];
+        walk_finish(w, memo, (R.ablate & 2) ? 0 : m.subpx, nb);
+        if (KIND == 1 && (w.live.t != 0.0 || w.live.v != 0.0))      // eval_lookup left K in the v slot; (0,0) = never evaluated
+            w.live.v = w.live.v / w.live.t;                         // Model.cpp:854
+        store_pixel(A, px, KIND, w, memo, nb);
+    }
+    }
+    if (od.mode == 1) od_record_visited(od, L, live);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,12 +420,21 @@ struct TiledState {
     bool ref_maps_ok = false;
     int ref_kind = -1, ref_K = 0;
     size_t ref_plane = 0;
+    // on-demand passes (umpa_ondemand.h): device scratch, and page-locked slots the counters of a timed match land in
+    void* od_buf = nullptr;   size_t od_cap = 0;
+    int* od_host = nullptr;   int od_slot = 0;
+    // the last match: passes computed / passes of the exhaustive table, parked pixels, missed tiles (umpa_hip_last_stats)
+    const int* stat_slots[64];  int stat_n = 0;
+    double stat_total_passes = 0.0;
 };
+#define UMPA_OD_SLOTS 256             // ring of counter slots (UMPA_OD_NCNT ints each) in TiledState::od_host
 
 // one entry per timed launch of a tiled match; the events come from the model's pool (`get`), so nothing is
 // created per launch and a match split into any number of row chunks is recorded completely
 struct TiledTimers {
-    struct Entry { int name; hipEvent_t t0, t1; double fma; };
+    // fma: FMAs of the launch; or, where that depends on what the device decided (on-demand passes), `fma_per` per pass and
+    // `counts` -> the counters of the chunk, copied to page-locked memory behind its last kernel (counts[OD_C_DONE] = passes computed)
+    struct Entry { int name; hipEvent_t t0, t1; double fma; const int* counts; double fma_per; };
     std::vector<Entry> entries;
     std::function<hipEvent_t()> get;
 };
@@ -428,7 +468,10 @@ inline void tiled_release(TiledState& st)
 {
     if (st.maps) (void)hipFree(st.maps);
     if (st.table) (void)hipFree(st.table);
+    if (st.od_buf) (void)hipFree(st.od_buf);
+    if (st.od_host) (void)hipHostFree(st.od_host);
     st.maps = st.table = nullptr;
+    st.od_buf = nullptr; st.od_host = nullptr; st.od_cap = 0;
     st.maps_cap = st.table_cap = 0;
     st.ref_maps_ok = false;
 }
@@ -458,10 +501,50 @@ inline std::mutex& tiled_attr_mutex()
     return mu;
 }
 
+inline OdCorr od_corr_args(const OdArgs& od)
+{
+    OdCorr c;
+    c.done = od.done; c.items = od.items; c.nitems = od.cnt_out ? od.cnt_out + OD_C_ITEMS : nullptr;
+    c.ndone = od.cnt0 ? od.cnt0 + OD_C_DONE : nullptr; c.mode = od.mode;
+    c.r0 = od.r0; c.c0 = od.c0;
+    c.nsx = od_seed_count(od.ntx, od.c0);
+    c.nseed = c.nsx * od_seed_count(od.nty, od.r0);
+    return c;
+}
+
+struct CorrLaunch {
+    OdArgs od;                // od.mode 0: every pass (static grid); 3: seed tiles (compact static grid); 2: queue over od.items
+    bool dry;                 // only report the geometry
+    int tc, ub, nbatch, npass, ntx, nty;   // out: tile columns, column offsets per pass, ... of the shape that was picked
+    double fma_per_pass;      // out: fp64 FMAs one (tile, pass) executes (roofline accounting)
+};
+
+inline int device_cu_count()
+{
+    static int n[64] = {};
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    if (!n[devid & 63]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess || v <= 0) v = 256;
+        n[devid & 63] = v;
+    }
+    return n[devid & 63];
+}
+
 template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
-inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep, hipStream_t s, double* fma)
+inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>;
+    A.ntx = (A.N1 + TC - 1) / TC;
+    A.nty = (A.rows + C::TR - 1) / C::TR;
+    const int UJ = 2 * dev.ms - 1, nbatch = (UJ + UB - 1) / UB, npass = ((UJ + UI - 1) / UI) * nbatch;
+    L.tc = TC; L.ub = UB; L.nbatch = nbatch; L.npass = npass; L.ntx = A.ntx; L.nty = A.nty;
+    // fp64 FMAs of one (tile, pass): the products of the active threads over all frames, the column filter on QR rows
+    // and the row filter on the tile, for every plane of the pass (roofline accounting)
+    L.fma_per_pass = (double)C::QR * C::NQB * C::QB * UB * UI * dev.Na +
+                     (double)C::NPL * C::QR * TC * C::S + (double)C::NPL * C::TR * TC * C::S;
+    if (L.dry) return hipSuccess;
     static bool attr_set[64] = {};                                    // the attribute is per device
     int devid = 0;
     (void)hipGetDevice(&devid);
@@ -474,19 +557,25 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
             attr_set[devid & 63] = true;
         }
     }
-    A.ntx = (A.N1 + TC - 1) / TC;
-    A.nty = (A.rows + C::TR - 1) / C::TR;
-    const int UJ = 2 * dev.ms - 1, npass = ((UJ + UI - 1) / UI) * ((UJ + UB - 1) / UB);
-    const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
-    const int grid = 8 * tiles_per_xcd * npass;
-    if (fma) {
-        // fp64 FMAs this launch executes: per (tile, pass) the products of the active threads over all frames, the
-        // column filter on QR rows and the row filter on the tile, for every plane of the pass (roofline accounting)
-        const double per_pass = (double)C::QR * C::NQB * C::QB * UB * UI * dev.Na +
-                                (double)C::NPL * C::QR * TC * C::S + (double)C::NPL * C::TR * TC * C::S;
-        *fma = per_pass * (double)A.ntx * A.nty * npass;
+    const OdCorr oc = od_corr_args(L.od);
+    if (L.od.mode == 2) {                                             // persistent grid over the work list: one workgroup per slot of the chip
+        static bool qattr_set[64] = {};
+        {
+            std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+            if (!qattr_set[devid & 63]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_queue_kernel<NW, UB, TC, NTG, UI, WPC, NF>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+                if (e != hipSuccess) return e;
+                qattr_set[devid & 63] = true;
+            }
+        }
+        const int grid = ((device_cu_count() * WPC + 7) / 8) * 8;
+        hipLaunchKernelGGL((corr_volume_queue_kernel<NW, UB, TC, NTG, UI, WPC, NF>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
+    } else {
+        const int nt = L.od.mode == 3 ? oc.nseed : A.ntx * A.nty;
+        const int grid = 8 * ((nt + 7) / 8) * npass;
+        if (nt > 0) hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
     }
-    hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
     return hipGetLastError();
 }
 
@@ -508,35 +597,35 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // (planes to LDS 3.5 k, column filter 5.2 k, write back 2.5 k, row filter + stores 9.6 k).
 #define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 2) X(2, 24, 256, 1, 2, 2) X(3, 16, 256, 1, 2, 1) X(4, 32, 512, 1, 1, 2)
 template <int NW, int UB>
-inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
+inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     const int want = tiled_corr_shape();
 #define UMPA_TRY_SHAPE(id, TC, NTG, UI, WPC, NF)                                                        \
     if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>::OK) {                                          \
-        if (want == 0 || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF>(dev, A, sep, s, fma);  \
+        if (want == 0 || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF>(dev, A, sep, s, L);  \
     }
     UMPA_CORR_SHAPES(UMPA_TRY_SHAPE)
 #undef UMPA_TRY_SHAPE
-    return launch_corr<NW, UB, 32, 512, 1, 1, 2>(dev, A, sep, s, fma);
+    return launch_corr<NW, UB, 32, 512, 1, 1, 2>(dev, A, sep, s, L);
 }
 
 template <int NW>
-inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, double* fma)
+inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     if (ub == 9) {
-        if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s, fma);
+        if constexpr (CorrCfg<NW, 9, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 9>(dev, A, sep, s, L);
         ub = 8;
     }
     if (ub == 8) {
-        if constexpr (CorrCfg<NW, 8, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 8>(dev, A, sep, s, fma);
+        if constexpr (CorrCfg<NW, 8, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 8>(dev, A, sep, s, L);
         ub = 7;
     }
     if (ub == 7) {
-        if constexpr (CorrCfg<NW, 7, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s, fma);
+        if constexpr (CorrCfg<NW, 7, 32, 512, 1, 1, 2>::OK) return launch_corr_shape<NW, 7>(dev, A, sep, s, L);
         ub = 5;
     }
     static_assert(CorrCfg<NW, 5, 32, 512, 1, 1, 2>::OK, "UB=5 must always fit");
-    return launch_corr_shape<NW, 5>(dev, A, sep, s, fma);
+    return launch_corr_shape<NW, 5>(dev, A, sep, s, L);
 }
 
 template <int KIND, int NW>
@@ -575,6 +664,88 @@ inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& s
     case 8: { constexpr int NWC = 8; CALL; } break; \
     default: break;                             \
     }
+
+// ------------------------------------------------------------------------------------------------
+// on-demand passes (umpa_ondemand.h): scratch and the launch sequence shared by the plain and the masked path
+// ------------------------------------------------------------------------------------------------
+// Measured on one MI355X (round 3): where a pass is expensive and the replay cheap -- models with masks:
+// dark-field C2 + mask 41.8 -> 25.2 ms, plain 11.5 -> 8.2 ms -- leaving out ~40 % of the passes pays; on the plain
+// path the serial small launches (seed tiles, repair rounds: ~0.5 ms on C2, ~7 ms on C3) cost what the table kernel
+// saves (C2 3.44 -> 3.46 ms, C3 48.0 -> 46.7 ms), so it is off there unless UMPA_HIP_ONDEMAND=1 asks for it.
+inline bool od_enabled(int ntiles, int npass, bool masked)
+{
+    const char* e = getenv("UMPA_HIP_ONDEMAND");                      // 0: never, 1: whenever a tile has 2..64 passes (read per match: the tests switch it)
+    if (npass > 64 || npass < 2) return false;
+    if (e && atoi(e) == 0) return false;
+    if (e && atoi(e) == 1) return ntiles >= 2;
+    return masked && ntiles >= 6;                                     // a few tiles at least: one of them is a seed tile
+}
+
+// device scratch for `ntiles` tiles of `npass` passes and `npx` region pixels; fills the pointers of `od`
+#define UMPA_OD_NCNT (8 * (OD_ROUNDS + 1))                           // counters of a chunk: int[8] per stage
+struct OdBuffers { int* tiles[2]; int* px[2]; int* counters; size_t zero_bytes; };
+
+inline int od_reserve(TiledState& st, int ntiles, int npass, size_t npx, OdArgs& od, OdBuffers& B)
+{
+    const size_t nt = (size_t)ntiles;
+    B.zero_bytes = nt * 8 * 2 + nt * 4 + UMPA_OD_NCNT * 4;            // done, visited, tile_flag, counters: cleared per chunk
+    const size_t need = B.zero_bytes + 2 * nt * 4 + nt * npass * 4 + 2 * npx * 4 + 64;
+    if (st.od_cap < need) {
+        if (st.od_buf) (void)hipFree(st.od_buf);
+        st.od_buf = nullptr; st.od_cap = 0;
+        if (hipMalloc(&st.od_buf, need) != hipSuccess) return -3;
+        st.od_cap = need;
+    }
+    if (!st.od_host && hipHostMalloc((void**)&st.od_host, UMPA_OD_SLOTS * UMPA_OD_NCNT * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        st.od_host = nullptr;
+        return -3;
+    }
+    char* b = (char*)st.od_buf;
+    od.done = (unsigned long long*)b;
+    od.visited = od.done + nt;
+    od.tile_flag = (int*)(od.visited + nt);
+    B.counters = od.tile_flag + nt;
+    B.tiles[0] = B.counters + UMPA_OD_NCNT; B.tiles[1] = B.tiles[0] + nt;
+    od.items = B.tiles[1] + nt;
+    B.px[0] = od.items + nt * npass; B.px[1] = B.px[0] + npx;
+    od.cnt0 = B.counters;
+    return 0;
+}
+
+// One row chunk with on-demand passes.  corr(od) launches the table kernel (od.mode 3: static grid over the seed tiles;
+// 2: persistent grid over od.items), replay(od) the walk kernel in od.mode 1 / 2 / 3.  Both return a hipError_t.
+template <class Corr, class Replay>
+inline hipError_t od_run_chunk(OdArgs od, const OdBuffers& B, hipStream_t s, Corr corr, Replay replay)
+{
+    hipError_t e = hipMemsetAsync(od.done, 0, B.zero_bytes, s);
+    if (e != hipSuccess) return e;
+    const int ntiles = od.ntx * od.nty, lb = (ntiles + 255) / 256;
+    od.r0 = std::min(1, od.nty - 1); od.c0 = std::min(1, od.ntx - 1);
+    { static const char* pe = getenv("UMPA_HIP_OD_PRED"); od.nearest = pe ? atoi(pe) : 1; }   // tuning: 0 = union over the seed tiles around
+    auto stage = [&](int r) { return B.counters + 8 * r; };
+    // 1. seed tiles: every pass (a compact grid over them); their pixels record what they read
+    od.cnt_in = nullptr; od.cnt_out = stage(0);
+    od.tile_in = nullptr; od.tile_out = B.tiles[0]; od.px_in = nullptr; od.px_out = B.px[0];
+    od.mode = 3; if ((e = corr(od)) != hipSuccess) return e;
+    od.mode = 1; if ((e = replay(od)) != hipSuccess) return e;
+    // 2. + 3. the other tiles: what the seed tiles around them visited; a walk that needs more parks its pixel
+    hipLaunchKernelGGL(od_list_kernel, dim3(lb), dim3(256), 0, s, od, 1);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    od.mode = 2; if ((e = corr(od)) != hipSuccess) return e;
+    od.mode = 2; if ((e = replay(od)) != hipSuccess) return e;
+    // 4. repair rounds: what the parked pixels asked for (the last round: everything the missed tiles lack), then
+    // the parked pixels again from the start
+    for (int r = 1; r <= OD_ROUNDS; r++) {
+        od.cnt_in = stage(r - 1); od.cnt_out = stage(r);
+        od.tile_in = B.tiles[(r - 1) & 1]; od.tile_out = B.tiles[r & 1];
+        od.px_in = B.px[(r - 1) & 1]; od.px_out = B.px[r & 1];
+        hipLaunchKernelGGL(od_list_kernel, dim3(lb), dim3(256), 0, s, od, r == OD_ROUNDS ? 3 : 2);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        od.mode = 2; if ((e = corr(od)) != hipSuccess) return e;
+        od.mode = 3; if ((e = replay(od)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 inline size_t tiled_table_budget()
 {
@@ -655,7 +826,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     auto tic = [&](int name) {
         timing_open = false;
         if (!tt) return;
-        TiledTimers::Entry en = {name, tt->get(), tt->get(), 0.0};
+        TiledTimers::Entry en = {name, tt->get(), tt->get(), 0.0, nullptr, 0.0};
         if (!en.t0 || !en.t1) return;
         (void)hipEventRecord(en.t0, s);
         tt->entries.push_back(en);
@@ -680,6 +851,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
 
     int ub = pick_ub(UJ);
     { const char* e = getenv("UMPA_HIP_UB"); if (e) ub = atoi(e); }      // tuning override: 9, 8, 7 or 5
+    st.stat_n = 0; st.stat_total_passes = 0.0;
     for (int drow0 = 0; drow0 < N0d; drow0 += (int)rows_chunk) {
         const int drows = (int)((N0d - drow0 < rows_chunk) ? N0d - drow0 : rows_chunk);
         CorrArgs CA;
@@ -689,40 +861,77 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         CA.br0 = box.r0; CA.br1 = box.r1; CA.bc0 = box.c0; CA.bc1 = box.c1; CA.Wf = box.Wf;
         { const char* ab = getenv("UMPA_HIP_ABLATE"); CA.ablate = ab ? atoi(ab) : 0; }
         CA.ntx = CA.nty = 0;                                          // set by launch_corr for the tile shape it picks
-        e = hipErrorInvalidValue;
-        double corr_fma = 0.0;
-        tic(3);
-        UMPA_NW_SWITCH(Nw, (e = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s, &corr_fma)))
-        toc(corr_fma);
-        if (e != hipSuccess) return (int)e;
-
         // output rows whose dense row lies in [drow0, drow0 + drows)
         const int xi_lo = (drow0 + A.step0 - 1) / A.step0;
         const int xi_hi = std::min(A.N0, (drow0 + drows - 1) / A.step0 + 1);
-        if (xi_hi <= xi_lo) continue;
         ReplayArgs R;
         R.table = st.table; R.slot_stride = CA.slot_stride; R.drow0 = drow0; R.N1d = N1d;
-        R.row0 = xi_lo; R.rows = xi_hi - xi_lo;
+        R.row0 = xi_lo; R.rows = std::max(0, xi_hi - xi_lo);
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
-        dim3 blk(64, UMPA_REPLAY_ROWS), grd((A.N1 + 63) / 64, (R.rows + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
-        tic(4);
         // frame count as a template constant where the map planes are 32-bit addressable (eval_lookup)
         const bool small = (size_t)M.H * M.W * 2 * sizeof(double) < ((size_t)1 << 32);   // a pair plane
-#define UMPA_REPLAY_NA(n) case n: hipLaunchKernelGGL((replay_walk_kernel<1, n>), grd, blk, 0, s, dev, M, R, A); break;
-        if (kind == 1 && small && dev.Na <= UMPA_KTEMPL) {
-            switch (dev.Na) {
-                UMPA_REPLAY_NA(1) UMPA_REPLAY_NA(2) UMPA_REPLAY_NA(3) UMPA_REPLAY_NA(4) UMPA_REPLAY_NA(5) UMPA_REPLAY_NA(6)
-                UMPA_REPLAY_NA(7) UMPA_REPLAY_NA(8) UMPA_REPLAY_NA(9) UMPA_REPLAY_NA(10) UMPA_REPLAY_NA(11) UMPA_REPLAY_NA(12)
-                UMPA_REPLAY_NA(13) UMPA_REPLAY_NA(14) UMPA_REPLAY_NA(15) UMPA_REPLAY_NA(16) UMPA_REPLAY_NA(17) UMPA_REPLAY_NA(18)
-                UMPA_REPLAY_NA(19) UMPA_REPLAY_NA(20) UMPA_REPLAY_NA(21) UMPA_REPLAY_NA(22) UMPA_REPLAY_NA(23) UMPA_REPLAY_NA(24)
-            }
-        } else if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1, 0>), grd, blk, 0, s, dev, M, R, A);
-        else hipLaunchKernelGGL((replay_walk_kernel<0, 0>), grd, blk, 0, s, dev, M, R, A);
-#undef UMPA_REPLAY_NA
-        toc();
-        e = hipGetLastError();
+
+        CorrLaunch CL;
+        memset(&CL, 0, sizeof(CL));
+        CL.dry = true;                                                // which shape, how many passes?
+        e = hipErrorInvalidValue;
+        UMPA_NW_SWITCH(Nw, (e = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s, CL)))
         if (e != hipSuccess) return (int)e;
-        if (on_rows) on_rows(xi_lo, xi_hi);
+        CL.dry = false;
+        const int ntiles = CL.ntx * CL.nty;
+        const int* counts = nullptr;
+
+        auto corr = [&](const OdArgs& od) {
+            CL.od = od;
+            hipError_t ce = hipErrorInvalidValue;
+            tic(3);
+            UMPA_NW_SWITCH(Nw, (ce = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s, CL)))
+            toc(od.mode ? 0.0 : CL.fma_per_pass * ntiles * CL.npass);
+            return ce;
+        };
+        auto replay = [&](const OdArgs& od) {
+            if (R.rows <= 0) return hipSuccess;
+            dim3 blk(64, UMPA_REPLAY_ROWS), grd((A.N1 + 63) / 64, (R.rows + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
+            if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);   // queue over the parked pixels
+            if (od.mode == 1) { blk = dim3(64, 1); grd = dim3((32 * od.tc + 63) / 64, od_seed_count(od.ntx, od.c0) * od_seed_count(od.nty, od.r0)); if (!grd.y) return hipSuccess; }
+            tic(4);
+#define UMPA_REPLAY_NA(n) case n: hipLaunchKernelGGL((replay_walk_kernel<1, n>), grd, blk, 0, s, dev, M, R, A, od); break;
+            if (kind == 1 && small && dev.Na <= UMPA_KTEMPL) {
+                switch (dev.Na) {
+                    UMPA_REPLAY_NA(1) UMPA_REPLAY_NA(2) UMPA_REPLAY_NA(3) UMPA_REPLAY_NA(4) UMPA_REPLAY_NA(5) UMPA_REPLAY_NA(6)
+                    UMPA_REPLAY_NA(7) UMPA_REPLAY_NA(8) UMPA_REPLAY_NA(9) UMPA_REPLAY_NA(10) UMPA_REPLAY_NA(11) UMPA_REPLAY_NA(12)
+                    UMPA_REPLAY_NA(13) UMPA_REPLAY_NA(14) UMPA_REPLAY_NA(15) UMPA_REPLAY_NA(16) UMPA_REPLAY_NA(17) UMPA_REPLAY_NA(18)
+                    UMPA_REPLAY_NA(19) UMPA_REPLAY_NA(20) UMPA_REPLAY_NA(21) UMPA_REPLAY_NA(22) UMPA_REPLAY_NA(23) UMPA_REPLAY_NA(24)
+                }
+            } else if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1, 0>), grd, blk, 0, s, dev, M, R, A, od);
+            else hipLaunchKernelGGL((replay_walk_kernel<0, 0>), grd, blk, 0, s, dev, M, R, A, od);
+#undef UMPA_REPLAY_NA
+            toc();
+            return hipGetLastError();
+        };
+
+        OdArgs od;
+        memset(&od, 0, sizeof(od));
+        od.tc = CL.tc; od.ub = CL.ub; od.nbatch = CL.nbatch; od.npass = CL.npass; od.ntx = CL.ntx; od.nty = CL.nty;
+        od.ub_inv = (65536 + CL.ub - 1) / CL.ub;
+        OdBuffers OB;
+        if (od_enabled(ntiles, CL.npass, false) && !CA.ablate) {
+            if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
+            if ((e = od_run_chunk(od, OB, s, corr, replay)) != hipSuccess) return (int)e;
+            // the counters of this chunk, for the FMA count of a timed match and for umpa_hip_last_stats
+            int* slot = st.od_host + UMPA_OD_NCNT * (st.od_slot++ % UMPA_OD_SLOTS);
+            if ((e = hipMemcpyAsync(slot, OB.counters, UMPA_OD_NCNT * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+            counts = slot;
+            if (st.stat_n < 64) st.stat_slots[st.stat_n++] = slot;
+            if (tt) for (auto it = tt->entries.rbegin(); it != tt->entries.rend(); ++it)
+                if (it->name == 3) { it->counts = counts; it->fma_per = CL.fma_per_pass; break; }   // all FMAs of the chunk on its last table launch
+        } else {
+            od.mode = 0;
+            if ((e = corr(od)) != hipSuccess) return (int)e;
+            if ((e = replay(od)) != hipSuccess) return (int)e;
+        }
+        st.stat_total_passes += (double)ntiles * CL.npass;
+        if (xi_hi > xi_lo && on_rows) on_rows(xi_lo, xi_hi);
     }
     return 0;
 }
@@ -745,12 +954,25 @@ inline bool masked_supported(int Nw)
 }
 
 template <int KIND, int NW>
-inline hipError_t launch_masked(const ModelDev& dev, MaskedArgs A, const Sep1D& sep, hipStream_t s, double* fma)
+inline hipError_t launch_masked(const ModelDev& dev, MaskedArgs A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     constexpr int UBM = masked_ub<KIND, NW>();
     using C = MaskCfg<KIND, NW, UBM>;
     if constexpr (!C::OK) return hipErrorInvalidValue;
     else {
+        A.ntx = (A.N1 + C::TC - 1) / C::TC;
+        A.nty = (A.rows + C::TR - 1) / C::TR;
+        const int UJ = 2 * dev.ms - 1, nbatch = (UJ + UBM - 1) / UBM, npass = UJ * nbatch;
+        L.tc = C::TC; L.ub = UBM; L.nbatch = nbatch; L.npass = npass; L.ntx = A.ntx; L.nty = A.nty;
+        // fp64 issue slots (FMA, multiply or add each counted once) of one (tile, pass) with UBM column offsets: per frame
+        // and column offset the products of the active threads (pair weight 6 + 7) and, DF, three planes through both
+        // filters + the fold into t2, t4, t6, wt; at the end NPL planes through both filters and the solve
+        const double filt = (double)C::QR * C::TC * C::S + (double)C::TR * C::TC * C::S;
+        const double prod = (double)C::QR * C::NQB * C::QB * 13.0;
+        const double per_shift_frame = prod + (KIND == 1 ? 3.0 * filt + 2.0 * C::TR * C::TC * 4.0 : 0.0);
+        const double per_shift_end = C::NPL * filt + 20.0 * C::TR * C::TC;
+        L.fma_per_pass = (per_shift_frame * dev.Na + per_shift_end) * (double)UJ / nbatch;    // (UJ real column offsets over nbatch passes)
+        if (L.dry) return hipSuccess;
         static bool attr_set[64] = {};
         int devid = 0;
         (void)hipGetDevice(&devid);
@@ -763,22 +985,25 @@ inline hipError_t launch_masked(const ModelDev& dev, MaskedArgs A, const Sep1D& 
                 attr_set[devid & 63] = true;
             }
         }
-        A.ntx = (A.N1 + C::TC - 1) / C::TC;
-        A.nty = (A.rows + C::TR - 1) / C::TR;
-        const int UJ = 2 * dev.ms - 1, nbatch = (UJ + UBM - 1) / UBM, npass = UJ * nbatch;
-        const int tiles_per_xcd = (A.ntx * A.nty + 7) / 8;
-        const int grid = 8 * tiles_per_xcd * npass;
-        if (fma) {
-            // fp64 issue slots (FMA, multiply or add each counted once) this launch executes, per (tile, row offset):
-            // per frame and real column offset the products of the active threads (pair weight 6 + 7) and, DF, three
-            // planes through both filters + the fold into t2, t4, t6; at the end NPL (+1) planes through both filters
-            const double filt = (double)C::QR * C::TC * C::S + (double)C::TR * C::TC * C::S;
-            const double prod = (double)C::QR * C::NQB * C::QB * 13.0;
-            const double per_shift_frame = prod + (KIND == 1 ? 3.0 * filt + 2.0 * C::TR * C::TC * 3.0 : 0.0);
-            const double per_shift_end = (KIND == 1 ? 2.0 : 1.0) * C::NPL * filt + 20.0 * C::TR * C::TC;
-            *fma = (per_shift_frame * dev.Na + per_shift_end) * UJ * UJ * (double)A.ntx * A.nty;
+        const OdCorr oc = od_corr_args(L.od);
+        if (L.od.mode == 2) {
+            static bool qattr_set[64] = {};
+            {
+                std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+                if (!qattr_set[devid & 63]) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_masked_queue_kernel<KIND, NW, UBM>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+                    if (e != hipSuccess) return e;
+                    qattr_set[devid & 63] = true;
+                }
+            }
+            const int grid = ((device_cu_count() + 7) / 8) * 8;             // one 512-thread workgroup per CU
+            hipLaunchKernelGGL((corr_masked_queue_kernel<KIND, NW, UBM>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
+        } else {
+            const int nt = L.od.mode == 3 ? oc.nseed : A.ntx * A.nty;
+            const int grid = 8 * ((nt + 7) / 8) * npass;
+            if (nt > 0) hipLaunchKernelGGL((corr_masked_kernel<KIND, NW, UBM>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
         }
-        hipLaunchKernelGGL((corr_masked_kernel<KIND, NW, UBM>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep);
         return hipGetLastError();
     }
 }
@@ -841,7 +1066,7 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
     auto tic = [&](int name) {
         timing_open = false;
         if (!tt) return;
-        TiledTimers::Entry en = {name, tt->get(), tt->get(), 0.0};
+        TiledTimers::Entry en = {name, tt->get(), tt->get(), 0.0, nullptr, 0.0};
         if (!en.t0 || !en.t1) return;
         (void)hipEventRecord(en.t0, s);
         tt->entries.push_back(en);
@@ -866,6 +1091,7 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
         }
         st.ref_maps_ok = true; st.ref_kind = kind; st.ref_K = K; st.ref_plane = plane;
     }
+    st.stat_n = 0; st.stat_total_passes = 0.0;
     for (int drow0 = 0; drow0 < N0d; drow0 += (int)rows_chunk) {
         const int drows = (int)((N0d - drow0 < rows_chunk) ? N0d - drow0 : rows_chunk);
         MaskedArgs MA;
@@ -876,24 +1102,61 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
         MA.br0 = box.r0; MA.br1 = box.r1; MA.bc0 = box.c0; MA.bc1 = box.c1; MA.Wf = box.Wf;
         MA.ntx = MA.nty = 0;
         { const char* ab = getenv("UMPA_HIP_ABLATE_MASKED"); MA.ablate = ab ? atoi(ab) : 0; }
-        e = hipErrorInvalidValue;
-        double fma = 0.0;
-        tic(6);
-        if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_masked<1, NWC>(dev, MA, st.sep, s, &fma))) }
-        else { UMPA_NW_SWITCH(Nw, (e = launch_masked<0, NWC>(dev, MA, st.sep, s, &fma))) }
-        toc(fma);
-        if (e != hipSuccess) return (int)e;
         const int xi_lo = (drow0 + A.step0 - 1) / A.step0;
         const int xi_hi = std::min(A.N0, (drow0 + drows - 1) / A.step0 + 1);
-        if (xi_hi <= xi_lo) continue;
-        dim3 blk(64), grd((A.N1 + 63) / 64, xi_hi - xi_lo);
-        tic(7);
-        if (kind == 1) hipLaunchKernelGGL((replay_cost_kernel<1>), grd, blk, 0, s, dev, (const double*)st.table, MA.slot_stride, drow0, N1d, xi_lo, xi_hi - xi_lo, A);
-        else hipLaunchKernelGGL((replay_cost_kernel<0>), grd, blk, 0, s, dev, (const double*)st.table, MA.slot_stride, drow0, N1d, xi_lo, xi_hi - xi_lo, A);
-        toc();
-        e = hipGetLastError();
+        const int rrows = std::max(0, xi_hi - xi_lo);
+
+        CorrLaunch CL;
+        memset(&CL, 0, sizeof(CL));
+        CL.dry = true;
+        e = hipErrorInvalidValue;
+        if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_masked<1, NWC>(dev, MA, st.sep, s, CL))) }
+        else { UMPA_NW_SWITCH(Nw, (e = launch_masked<0, NWC>(dev, MA, st.sep, s, CL))) }
         if (e != hipSuccess) return (int)e;
-        if (on_rows) on_rows(xi_lo, xi_hi);
+        CL.dry = false;
+        const int ntiles = CL.ntx * CL.nty;
+
+        auto corr = [&](const OdArgs& od) {
+            CL.od = od;
+            hipError_t ce = hipErrorInvalidValue;
+            tic(6);
+            if (kind == 1) { UMPA_NW_SWITCH(Nw, (ce = launch_masked<1, NWC>(dev, MA, st.sep, s, CL))) }
+            else { UMPA_NW_SWITCH(Nw, (ce = launch_masked<0, NWC>(dev, MA, st.sep, s, CL))) }
+            toc(od.mode ? 0.0 : CL.fma_per_pass * ntiles * CL.npass);
+            return ce;
+        };
+        auto replay = [&](const OdArgs& od) {
+            if (rrows <= 0) return hipSuccess;
+            dim3 blk(64), grd((A.N1 + 63) / 64, rrows);
+            if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);
+            if (od.mode == 1) { grd = dim3((32 * od.tc + 63) / 64, od_seed_count(od.ntx, od.c0) * od_seed_count(od.nty, od.r0)); if (!grd.y) return hipSuccess; }
+            tic(7);
+            if (kind == 1) hipLaunchKernelGGL((replay_cost_kernel<1>), grd, blk, 0, s, dev, (const double*)st.table, MA.slot_stride, drow0, N1d, xi_lo, rrows, A, od);
+            else hipLaunchKernelGGL((replay_cost_kernel<0>), grd, blk, 0, s, dev, (const double*)st.table, MA.slot_stride, drow0, N1d, xi_lo, rrows, A, od);
+            toc();
+            return hipGetLastError();
+        };
+
+        OdArgs od;
+        memset(&od, 0, sizeof(od));
+        od.tc = CL.tc; od.ub = CL.ub; od.nbatch = CL.nbatch; od.npass = CL.npass; od.ntx = CL.ntx; od.nty = CL.nty;
+        od.ub_inv = (65536 + CL.ub - 1) / CL.ub;
+        OdBuffers OB;
+        if (od_enabled(ntiles, CL.npass, true) && !MA.ablate) {
+            if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
+            if ((e = od_run_chunk(od, OB, s, corr, replay)) != hipSuccess) return (int)e;
+            int* slot = st.od_host + UMPA_OD_NCNT * (st.od_slot++ % UMPA_OD_SLOTS);
+            if ((e = hipMemcpyAsync(slot, OB.counters, UMPA_OD_NCNT * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+            if (st.stat_n < 64) st.stat_slots[st.stat_n++] = slot;
+            if (tt) for (auto it = tt->entries.rbegin(); it != tt->entries.rend(); ++it)
+                if (it->name == 6) { it->counts = slot; it->fma_per = CL.fma_per_pass; break; }
+        } else {
+            od.mode = 0;
+            if ((e = corr(od)) != hipSuccess) return (int)e;
+            if ((e = replay(od)) != hipSuccess) return (int)e;
+        }
+        st.stat_total_passes += (double)ntiles * CL.npass;
+        if (xi_hi > xi_lo && on_rows) on_rows(xi_lo, xi_hi);
     }
     return 0;
 }
