@@ -345,6 +345,8 @@ def sharded(args, world, rank, local, dev, backend):
         nc = ncalls.cpu().numpy()
         err_all = whole_e.cpu().numpy()
         npx = n_out * N1
+        agrees = None if args.no_cpu else verify_slab_boundaries(
+            world, H, W, K, Nw, ms, df, P, N1, nparam, st_s, whole_v, whole_e, cls, local)
         name = "C4" if (world == 8 and H == 8192 and W == 8192) else "C4-type"
         roof = roofline(kernels, args.steps, algorithmic_bytes(K, N0 + 2 * P, W, N0, N1, nparam), "C4slab")
         out = {
@@ -356,8 +358,9 @@ def sharded(args, world, rank, local, dev, backend):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d frames, Nw=%d, max_shift=%d, dark-field %s; input rows sharded %d per GPU, "
-                                   "halo exchange + slab match + gather on rank 0 per step" % (
-                                       name, H, W, K, Nw, ms, "on" if df else "off", H // world),
+                                   "halo exchange + slab match + gather on rank 0 per step (N GPUs match ONE (N x %d) x %d image: "
+                                   "N = 8 is BASELINE config C4's 8192 x 8192)" % (
+                                       name, H, W, K, Nw, ms, "on" if df else "off", H // world, H // world, W),
                        "output_pixels_total": npx, "output_pixels_per_gpu": N0 * N1, "kernel_path": path,
                        "parallelism": "rows x%d" % world, "comm_backend": "rccl" if backend == "nccl" else backend,
                        "rccl_world_size": world,
@@ -372,10 +375,52 @@ def sharded(args, world, rank, local, dev, backend):
                        "input_generation_s": round(t_gen, 1)},
             "roofline": roof,
             "cpu_baseline": None,
+            "gpu_agrees": agrees,
         }
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def verify_slab_boundaries(world, H, W, K, Nw, ms, df, P, N1, nparam, st, whole_v, whole_e, cls, local, half=8):
+    """Rank 0, after the timed steps: the maps it gathered must be RIGHT, not just there.  Around (up to) two slab
+    boundaries the input rows are generated again on the host (make_block of the two ranks that own them -- the inputs
+    never left their GPUs otherwise), matched UNSHARDED by a model of their own on this GPU, and the gathered maps of
+    the 2 * half output rows across the boundary must equal that match bit for bit (pixels are independent: sharding,
+    halo exchange and gather may not change a bit).  Raises on a mismatch; returns what was compared."""
+    import torch
+    from umpa_amd.synth import make_block
+    bounds = sorted(set([0, world - 2])) if world > 1 else []
+    checked = []
+    for r in bounds:
+        b = st.out[r][1]                                              # first output row of rank r + 1's slab
+        lo_out, hi_out = max(0, b - half), min(whole_e.shape[0], b + half)
+        lo_in, hi_in = lo_out, hi_out + 2 * P                         # image rows those output rows read
+        blocks = []
+        for q in (r, r + 1):
+            a0, a1 = st.own[q]
+            if a1 <= lo_in or a0 >= hi_in:
+                continue
+            sb, rb = make_block(st.own[q], H, W, K, ms, df=df, seed=100 * q)
+            c0, c1 = max(lo_in, a0) - a0, min(hi_in, a1) - a0
+            blocks.append((np.ascontiguousarray(sb[:, c0:c1]), np.ascontiguousarray(rb[:, c0:c1])))
+            del sb, rb
+        sam = np.ascontiguousarray(np.concatenate([x[0] for x in blocks], axis=1))
+        ref = np.ascontiguousarray(np.concatenate([x[1] for x in blocks], axis=1))
+        assert sam.shape[1] == hi_in - lo_in, (sam.shape, lo_in, hi_in)
+        m = cls(sam, ref, window_size=Nw, max_shift=ms, device=local)
+        m.debug = False
+        got = m.match(quiet=True)
+        keys = ("f", "T", "dx", "dy") + (("df",) if df else ())
+        gath_v = whole_v[lo_out:hi_out].cpu().numpy()
+        gath_e = whole_e[lo_out:hi_out].cpu().numpy()
+        if not np.array_equal(gath_e, got["err"]):
+            raise AssertionError("gathered err map differs from an unsharded match across the boundary of ranks %d|%d" % (r, r + 1))
+        for n, k in enumerate(keys):
+            if not np.array_equal(gath_v[:, :, n], got[k], equal_nan=True):
+                raise AssertionError("gathered %s map differs from an unsharded match across the boundary of ranks %d|%d" % (k, r, r + 1))
+        checked.append(dict(ranks=[r, r + 1], output_rows=[int(lo_out), int(hi_out)], pixels=int((hi_out - lo_out) * N1)))
+    return dict(parity="bit-identical to an unsharded match of regenerated input rows", boundaries=checked)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -383,7 +428,38 @@ def sharded(args, world, rank, local, dev, backend):
 # ------------------------------------------------------------------------------------------------
 def farm_bench(args, local):
     from umpa_amd import farm
-    print(json.dumps(farm.bench_c5(device=local, steps=args.steps, warmup=args.warmup)), flush=True)
+    if args.no_cpu:
+        print(json.dumps(farm.bench_c5(device=local, steps=args.steps, warmup=args.warmup)), flush=True)
+        return
+    # one projection of the series against the CPU checker: a band of full-width rows of its maps, held to the parity bar
+    line, kept = farm.bench_c5(device=local, steps=args.steps, warmup=args.warmup, keep=7)
+    from oracle import cpu_model, parity
+    kind = "reference" if cpu_model.have_ref() else "port"
+    ns = cpu_model.ref if kind == "reference" else cpu_model.port
+    info = host_info()
+    ncpu = usable_cpus(info)
+    cm = ns.UMPAModelDF(np.ascontiguousarray(kept["sam"]), np.ascontiguousarray(kept["ref"]), window_size=kept["Nw"], max_shift=kept["ms"])
+    cm.debug = True
+    N0, N1 = cm.extent
+    rows = min(N0, max(64, 4 * ncpu))
+    r0 = (N0 - rows) // 2
+    t = time.perf_counter()
+    want = cm.match(ROI=((r0, r0 + rows, 1), (0, N1, 1)), num_threads=ncpu, quiet=True)
+    dt = time.perf_counter() - t
+    # the streamed maps carry no debug arrays: the same projection through a model of its own (debug arrays on) must give
+    # the streamed maps bit for bit, and is then held to the parity bar against the CPU checker
+    from umpa_amd import model
+    gm = model.UMPAModelDF(np.ascontiguousarray(kept["sam"]), np.ascontiguousarray(kept["ref"]), window_size=kept["Nw"],
+                           max_shift=kept["ms"], device=local)
+    got = gm.match(ROI=((r0, r0 + rows, 1), (0, N1, 1)), quiet=True)
+    for k in ("f", "T", "dx", "dy", "df", "err"):
+        assert np.array_equal(kept["res"][k][r0:r0 + rows], got[k], equal_nan=True), "streamed map %s differs from a direct match" % k
+    st = parity.assert_parity(got, want, kept["ms"], "bench C5 projection 7")
+    line["cpu_baseline"] = dict(value=round(rows * N1 / dt / 1e6, 5), unit="Mpx/s", threads=ncpu, usable_cpus=ncpu, cores=ncpu, kind=kind,
+                                sample="projection 7 of the series: %d full-width output rows (%d px) in %.1f s, OpenMP dynamic over rows as "
+                                       "model.pyx:476-478" % (rows, rows * N1, dt), host=info,
+                                gpu_agrees=dict(rows=rows, parity="pass", ok_pixels=st["ok"], unconverged_newton_pixels=st["unconverged"]))
+    print(json.dumps(line), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -477,7 +553,7 @@ def cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1, per_run_s=2.5):
     got = m.match(ROI=((0, rows, 1), (0, N1, 1)), quiet=True)
     stats = parity.assert_parity(got, want, ms, "bench sample")       # raises (and fails the run) on a mismatch
     dT = float(np.max(np.abs(got["T"] - want["T"])[want["err"] == 1]))
-    return dict(value=round(best[0], 5), unit="Mpx/s", cores=best[1], kind=kind,
+    return dict(value=round(best[0], 5), unit="Mpx/s", cores=min(best[1], ncpu), threads=best[1], kind=kind,
                 sample="thread sweep on first-touch copies of the C-contiguous stacks, OMP_PROC_BIND=%s OMP_PLACES=%s; best: "
                        "first %d output rows (%d px) in %.1f s; OpenMP dynamic over rows as model.pyx:476-478" % (
                            os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), best[2], best[2] * N1, best[3]),

@@ -80,12 +80,16 @@ def assert_parity(got, want, max_shift, label="", allow_illposed=None, subpx=-1,
         assert "debug_a" in got and "debug_d" in got, \
             "%s: %d in-box ok pixels miss the 1e-5 bar (no debug arrays to classify them)" % (label, miss.sum())
         for (xi, xj) in np.argwhere(miss):
-            illposed = newton_unconverged(got["debug_a"][xi, xj], got["debug_d"][xi, xj])
-            if not illposed and "debug_a" in want and "debug_d" in want:
-                # the reference's own neighbourhood (it differs from ours in the last bits): unconverged there, or a
-                # Newton trajectory that does not survive rounding noise (newton_unstable)
+            # the REFERENCE's own 4x4 neighbourhood decides first (it differs from the candidate's in the last bits):
+            # unconverged there, or a Newton trajectory that does not survive rounding noise (newton_unstable); only a
+            # reference result without debug arrays (the farm's maps) falls back on the candidate's
+            if "debug_a" in want and "debug_d" in want:
                 illposed = (newton_unconverged(want["debug_a"][xi, xj], want["debug_d"][xi, xj]) or
                             newton_unstable(want["debug_a"][xi, xj], want["debug_d"][xi, xj]))
+                if not illposed:                                      # ... or unconverged on the candidate's neighbourhood
+                    illposed = newton_unconverged(got["debug_a"][xi, xj], got["debug_d"][xi, xj])
+            else:
+                illposed = newton_unconverged(got["debug_a"][xi, xj], got["debug_d"][xi, xj])
             if not illposed:
                 raise AssertionError("%s: pixel (%d,%d) misses the 1e-5 bar although the reference's Newton "
                                      "iteration is converged there: dx %r vs %r, dy %r vs %r, f %r vs %r" % (

@@ -92,14 +92,64 @@ def test_hip_bad_pixels_argument_errors(hip_align):
     ("normal_roi", "UMPA_normal", dict(ROI=(slice(2, 30, 1), slice(None, None, 1)))),
 ])
 def test_hip_help_functions_match_reference_golden(hip_align, name, fn, kw):
-    res = getattr(hip_align, fn)(G["hf_sam"], G["hf_ref"], window=2, shift=3, num_threads=1, **kw)
+    """The full bar on the repaired dx / dy.  A pixel of the final map may differ from the reference's only if that is
+    EXPLAINED: its raw value -- or, because a repaired pixel is the median of its neighbours, the raw value of one of its
+    four neighbours -- is (a) a pixel the parity checker classifies as ill-posed in the raw match (unconverged Newton,
+    counted and capped there), or (b) within 1e-5 of the repair threshold, so that it may fall on either side of it.
+    Everything else must agree to 1e-5, and the explained set must stay small."""
+    from conftest import assert_parity
+    from oracle import cpu_model
+    from umpa_amd import model
+    shift = 3
+    res = getattr(hip_align, fn)(G["hf_sam"], G["hf_ref"], window=2, shift=shift, num_threads=1, **kw)
     want = {k: G["hf_%s_%s" % (name, k)] for k in ("dx", "dy", "T", "df", "err")}
     assert np.array_equal(res["err"], want["err"])
     ok = want["err"] == 1
     for k in ("T", "df"):
         assert np.allclose(res[k][ok], want[k][ok], rtol=1e-5, atol=0), k
-    # dx / dy went through the repair: a pixel within 1e-5 of the threshold may fall on the other side
+
+    # the raw (un-repaired) maps of both sides: the HIP model and the CPU oracle, each as the helper builds them
+    def raw(ns):
+        out = []
+        pairs = [(G["hf_sam"], "sam")] if fn == "UMPA_normal" else [(G["hf_ref"], "bias"), (G["hf_sam"], "sam")]
+        for stack, role in pairs:
+            m = ns.UMPAModelDF(stack, G["hf_ref"], window_size=2, max_shift=shift)
+            if role == "sam":
+                m.assign_coordinates = kw.get("assign_coordinates", "sam")
+            out.append(m.match(ROI=kw.get("ROI", (slice(None), slice(None))), quiet=True))
+        return out
+    raw_g, raw_o = raw(model), raw(cpu_model.port)
+    suspect = np.zeros(want["dx"].shape, dtype=bool)
+    for g, o in zip(raw_g, raw_o):
+        assert_parity(g, o, shift, "align %s raw" % name)           # raises unless every differing pixel is ill-posed (and few)
+        for k in ("dx", "dy"):
+            suspect |= ~(np.abs(g[k] - o[k]) <= 1e-5 * np.maximum(1.0, np.abs(o[k])))
+    for k in ("dx", "dy"):
+        r = raw_o[-1][k] - (raw_o[0][k] if len(raw_o) == 2 else 0.0)
+        suspect |= np.abs(np.abs(r) - shift) <= 1e-5 * shift          # may fall on either side of the threshold
+    # one repair pass: a pixel's value depends on its four neighbours (edges reflect)
+    near = suspect.copy()
+    pad = np.pad(suspect, 1, mode="reflect")
+    near |= pad[:-2, 1:-1] | pad[2:, 1:-1] | pad[1:-1, :-2] | pad[1:-1, 2:]
+    assert near.mean() < 0.03, near.mean()
     for k in ("dx", "dy"):
         close = np.abs(res[k] - want[k]) <= 1e-5 * np.maximum(1.0, np.abs(want[k]))
-        assert close.mean() > 0.98, (k, close.mean())
+        assert np.all(close | near), (k, int((~close & ~near).sum()))
         assert np.abs(res[k]).max() <= max(3.0, np.abs(want[k]).max()) + 1e-9
+
+
+@pytest.mark.gpu
+def test_nobias_takes_device_tensors_and_reports_shape_errors(hip_align):
+    """the one-model shortcut of UMPA_nobias needs frames the library owns; frames that live on the GPU
+    already (torch tensors, borrowed) must still work, and a shape mismatch must raise the reference's message."""
+    import torch
+    sam, ref = G["hf_sam"], G["hf_ref"]
+    want = hip_align.UMPA_nobias(sam, ref, window=2, shift=3)
+    dev = torch.device("cuda", 0)
+    ts = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in sam]
+    tr = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in ref]
+    got = hip_align.UMPA_nobias(ts, tr, window=2, shift=3)
+    for k in ("dx", "dy", "T", "df", "err"):
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    with pytest.raises(RuntimeError, match="Incompatible shape"):
+        hip_align.UMPA_nobias(sam[:, :-2, :].copy(), ref, window=2, shift=3)

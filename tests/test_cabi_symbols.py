@@ -51,3 +51,19 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "umpaor_" not in txt and "umparef_" not in txt, f
+
+
+def test_reference_import_name_alias():
+    """`import UMPA` / `from UMPA import model` / `UMPA.match` resolve to umpa_amd: callers written against the reference
+    (speckle_matching.py:9, umpa_multi.py:149) keep their import lines.  The alias holds no code of its own."""
+    import UMPA
+    from UMPA import align, model
+    from UMPA.model import UMPAModelDF
+    import umpa_amd
+    assert UMPA.match is umpa_amd.match and UMPA.match_unbiased is umpa_amd.match_unbiased
+    assert model.UMPAModelNoDF is umpa_amd.model.UMPAModelNoDF and UMPAModelDF is umpa_amd.UMPAModelDF
+    assert align.UMPA_nobias is umpa_amd.align.UMPA_nobias
+    for f in os.listdir(os.path.join(REPO, "UMPA")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(REPO, "UMPA", f)).read()
+            assert "def " not in txt and "class " not in txt and "oracle" not in txt, f

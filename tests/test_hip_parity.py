@@ -276,11 +276,11 @@ def test_C5_shape_step_scan_against_the_oracle(hip_ns, port_ns):
         assert (~close & ok).sum() <= 4
 
 
-@pytest.mark.parametrize("name", ["B_walks", "C_mask", "D_stepping", "A_small"])
+@pytest.mark.parametrize("name", ["B_walks", "D_stepping", "A_small"])
 def test_staged_and_plain_direct_kernels_are_identical(hip_ns, name):
     """The general kernel with the windows served from LDS (path 3) sums the same terms in the same order as the one
-    that reads them through L1 (path 1): bit-identical maps, for masks, sample stepping with unequal shapes, both
-    coordinate conventions, steps and start shifts."""
+    that reads them through L1 (path 1): bit-identical maps, for sample stepping with unequal shapes, both coordinate
+    conventions, steps and start shifts.  (Masked models never take the staged kernel: umpa_masked.h is their path.)"""
     from umpa_amd import _lib
     case = Case(name)
     for n, v in enumerate(case.variants):

@@ -8,6 +8,8 @@ import os
 import socket
 import sys
 
+import time
+
 import numpy as np
 import pytest
 
@@ -116,6 +118,30 @@ def test_slab_bounds_partition():
     # BASELINE config C4: 8172 output rows over 8 GPUs -> 4 x 1022 + 4 x 1021, 10 halo rows each side
     assert [slab_bounds(8172, 8, g)[1] - slab_bounds(8172, 8, g)[0] for g in range(8)] == [1022] * 4 + [1021] * 4
     assert input_rows(8172, 10, 8, 3) == (3 * 1022, 4 * 1022 + 20)
+
+
+def test_projection_farm_failure_modes():
+    """a farm whose workers die at start-up raises instead of spinning; ids may repeat; ROI / step are
+    refused (the result slots hold full-extent maps)."""
+    from oracle import cpu_model
+    from umpa_amd.farm import ProjectionFarm
+    from umpa_amd.synth import make_stack
+    cpu_model.native("port")
+    Nw, ms = 2, 3
+    sam, ref, _ = make_stack(40, 44, 3, ms, df=True, seed=7, amplitude=1.0)
+    t0 = time.time()
+    with ProjectionFarm(ref, Nw, ms, devices=[None, None], model=("no_such_module_anywhere", "X")) as farm:
+        with pytest.raises(RuntimeError, match="farm worker|exited"):
+            dict(farm.map([(0, sam), (1, sam)], timeout=60.0))
+    assert time.time() - t0 < 60.0
+    with ProjectionFarm(ref, Nw, ms, devices=[None], model=("oracle.cpu_model", "port.UMPAModelDF")) as farm:
+        got = list(farm.map([(5, sam), (5, 0.5 * sam), (5, sam)], num_threads=1))       # the same id three times
+        assert [g[0] for g in got] == [5, 5, 5]
+        want = cpu_model.port.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
+        assert sum(np.array_equal(g[1]["T"], want["T"]) for g in got) == 2
+        with pytest.raises(ValueError, match="full-extent"):
+            dict(farm.map([(0, sam)], step=2))
+        assert dict(farm.map([(9, sam)], num_threads=1))[9]["T"].shape == want["T"].shape   # still usable afterwards
 
 
 def test_projection_farm_on_cpu_workers():
@@ -299,11 +325,14 @@ def test_device_sharded_frames_over_rccl(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_sharded_leg_rehearsal(tmp_path):
-    """bench.py --gpus 2 end to end at a reduced size (two ranks on one GPU, gloo): the JSON line of the C4 leg"""
+@pytest.mark.parametrize("gather", ["pieces", "after"])
+def test_bench_sharded_leg_rehearsal(tmp_path, gather):
+    """bench.py --gpus 2 end to end at a reduced size (two ranks on one GPU, gloo): the JSON line of the C4 leg, with the
+    gather overlapped piece by piece and with the gather after the match.  The leg verifies itself: the gathered maps
+    across the slab boundary must equal an unsharded match of regenerated input rows bit for bit (`gpu_agrees`)."""
     import json
     import subprocess
-    env = dict(os.environ, UMPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, UMPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", UMPA_BENCH_GATHER=gather)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--rows", "128", "--cols", "512"]
@@ -316,3 +345,32 @@ def test_bench_sharded_leg_rehearsal(tmp_path):
     for k in ("halo_ms", "match_ms", "gather_ms"):
         assert d["config"][k] > 0
     assert d["value"] > 0 and d["roofline"]["kernel"] in ("corr_volume", "replay_walk", "prep_maps")
+    assert ("pieces" in d["config"]["gather_mode"]) == (gather == "pieces")
+    g = d["gpu_agrees"]
+    assert g["parity"].startswith("bit-identical") and g["boundaries"][0]["ranks"] == [0, 1] and g["boundaries"][0]["pixels"] == 16 * 492
+
+
+@pytest.mark.gpu
+def test_projection_farm_two_workers_on_one_gpu(port_ns):
+    """ProjectionFarm(devices=[0, 0]): two worker processes (each its own StreamingMatcher) share the one GPU of the test
+    box -- the multi-device farm of BASELINE config C5 in every respect but the second card -- against the CPU oracle."""
+    from umpa_amd.farm import ProjectionFarm
+    from umpa_amd.synth import make_stack
+    Nw, ms, K, n = 3, 4, 4, 160
+    stacks = [make_stack(n, n + 24, K, ms, df=True, seed=60 + 7 * p, amplitude=2.0) for p in range(5)]
+    ref = stacks[0][1]
+    sams = {p: np.ascontiguousarray(stacks[p][0]) for p in range(5)}
+    with ProjectionFarm(ref, Nw, ms, devices=[0, 0]) as farm:
+        res = dict(farm.map(sams.items()))
+        assert len(farm._workers) == 2
+    assert sorted(res) == list(range(5))
+    for p in range(5):
+        o = port_ns.UMPAModelDF(sams[p], ref, window_size=Nw, max_shift=ms)
+        o.debug = False
+        want = o.match(quiet=True)
+        np.testing.assert_array_equal(res[p]["err"], want["err"])
+        ok = want["err"] == 1
+        for k in ("T", "df"):
+            np.testing.assert_allclose(res[p][k][ok], want[k][ok], rtol=1e-5)
+        close = np.abs(res[p]["dx"] - want["dx"]) <= 1e-5 * np.maximum(1.0, np.abs(want["dx"]))
+        assert (~close & ok).sum() <= max(2, int(0.002 * ok.sum()))      # (the farm's maps carry no debug arrays to classify with)

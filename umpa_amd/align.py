@@ -90,11 +90,23 @@ def UMPA_nobias(sams, refs, window=1, shift=3, pos_list=None, mask_list=None, as
     kw = _model_kwargs(window, shift, pos_list, mask_list)
     # The reference builds two models (align.py:98-113).  Both matches share the reference stack: one model keeps it
     # (and the reference-side maps of the tiled path) resident on the GPU, matches it against itself first and then
-    # gets the sample stack swapped in -- same numbers, half the uploads and allocations.
-    PM = model.UMPAModelDF(refs, refs, **kw)
-    res_b = PM.match(num_threads=num_threads, ROI=ROI, quiet=True)
-    bdx, bdy = np.array(res_b['dx']), np.array(res_b['dy'])
-    PM.update_frames(sam_list=sams)
+    # gets the sample stack swapped in -- same numbers, half the uploads and allocations.  That needs frames the
+    # library owns (host arrays) of matching shapes; device tensors (borrowed, not copied) and anything the model
+    # constructor would reject go the reference's way, two models, so that its error messages apply.
+    sams_l, refs_l = list(sams), list(refs)
+    shared = (len(sams_l) == len(refs_l) and len(refs_l) > 0 and not hasattr(refs_l[0], "data_ptr")
+              and not hasattr(sams_l[0], "data_ptr")
+              and all(tuple(np.shape(a)) == tuple(np.shape(b)) for a, b in zip(sams_l, refs_l)))
+    if shared:
+        PM = model.UMPAModelDF(refs, refs, **kw)
+        res_b = PM.match(num_threads=num_threads, ROI=ROI, quiet=True)
+        bdx, bdy = np.array(res_b['dx']), np.array(res_b['dy'])
+        PM.update_frames(sam_list=sams)
+    else:
+        PM = model.UMPAModelDF(sams, refs, **kw)                      # raises the reference's messages on bad input
+        PMb = model.UMPAModelDF(refs, refs, **kw)
+        res_b = PMb.match(num_threads=num_threads, ROI=ROI, quiet=True)
+        bdx, bdy = np.array(res_b['dx']), np.array(res_b['dy'])
     PM.assign_coordinates = assign_coordinates
     res = PM.match(num_threads=num_threads, ROI=ROI, quiet=True)
     res['dx'] = correct_bad_pixels(res['dx'] - bdx, shift)

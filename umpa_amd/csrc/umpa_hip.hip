@@ -282,8 +282,9 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
     if (m->kind != UMPA_HIP_KIND_DFKERNEL && !m->has_mask && !no_staged && !(flags & UMPA_HIP_F_FORCE_PLAIN_DIRECT) &&
         (size_t)A.N0 * A.N1 >= 64 && staged_geometry(m, A, G, lds_bytes)) {
         hipError_t e;
-        if (m->kind == UMPA_HIP_KIND_NODF) e = m->has_mask ? launch_staged<0, true>(m, A, G, lds_bytes, s) : launch_staged<0, false>(m, A, G, lds_bytes, s);
-        else e = m->has_mask ? launch_staged<1, true>(m, A, G, lds_bytes, s) : launch_staged<1, false>(m, A, G, lds_bytes, s);
+        // (no masked instantiation: masked models never come here -- above -- and run on the tiled path, umpa_masked.h)
+        if (m->kind == UMPA_HIP_KIND_NODF) e = launch_staged<0, false>(m, A, G, lds_bytes, s);
+        else e = launch_staged<1, false>(m, A, G, lds_bytes, s);
         if (e != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "staged kernel: %s", hipGetErrorString(e));
         m->last_path = 3;
         return 0;

@@ -187,34 +187,54 @@ def _farm_worker(device, cfg, tasks, results, in_name, out_name):
             return a
 
         def stage(task):
-            pid, q_in, q_out, kw = task
+            seq, pid, q_in, q_out, kw = task
             raw, _ = slots_in.view(q_in, shape, dtype)
             return sm._stage(pid, raw)
 
+        def stage_or_report(task):
+            """(reference number, None) of a staged task, or (None, message) when its upload failed"""
+            try:
+                return stage(task), None
+            except Exception as e:                                  # this projection only: the worker goes on
+                import traceback
+                return None, repr(e) + "\n" + traceback.format_exc()
+
         cur = tasks.get()
-        cur_ref = stage(cur) if cur is not None else None
+        cur_ref, cur_err = stage_or_report(cur) if cur is not None else (None, None)
         while cur is not None:
-            pid, q_in, q_out, kw = cur
-            sm._switch_reference(cur_ref)
-            state["slot"], state["off"] = q_out, 0
-            sm.model._out_alloc = out_alloc
-            kw = dict(kw)
-            kw.setdefault("quiet", True)
-            sm.model.match_async(**kw)                              # adopts the staged stack; kernels + downloads enqueued
-            nxt, nxt_ref, have_next = None, None, False
+            seq, pid, q_in, q_out, kw = cur
+            matched = False
+            if cur_err is None:
+                try:
+                    sm._switch_reference(cur_ref)
+                    state["slot"], state["off"] = q_out, 0
+                    sm.model._out_alloc = out_alloc
+                    kw = dict(kw)
+                    kw.setdefault("quiet", True)
+                    sm.model.match_async(**kw)                      # adopts the staged stack; kernels + downloads enqueued
+                    matched = True
+                except Exception as e:
+                    import traceback
+                    cur_err = repr(e) + "\n" + traceback.format_exc()
+            nxt, nxt_ref, nxt_err, have_next = None, None, None, False
             try:
                 nxt = tasks.get_nowait()                            # upload the next projection while this one is matched
                 have_next = True
                 if nxt is not None:
-                    nxt_ref = stage(nxt)
+                    nxt_ref, nxt_err = stage_or_report(nxt)
             except _queue.Empty:
                 pass
-            sm.model.wait()
-            results.put(("done", pid, q_in, q_out, None))
+            if matched:
+                try:
+                    sm.model.wait()
+                except Exception as e:
+                    import traceback
+                    cur_err = repr(e) + "\n" + traceback.format_exc()
+            results.put(("done", seq, q_in, q_out, cur_err))
             if not have_next:
                 nxt = tasks.get()
-                nxt_ref = stage(nxt) if nxt is not None else None
-            cur, cur_ref = nxt, nxt_ref
+                nxt_ref, nxt_err = stage_or_report(nxt) if nxt is not None else (None, None)
+            cur, cur_ref, cur_err = nxt, nxt_ref, nxt_err
     except Exception as e:                                          # a worker that cannot run must not hang the farm
         import traceback
         results.put(("error", None, None, None, repr(e) + "\n" + traceback.format_exc()))
@@ -239,7 +259,7 @@ def _cpu_worker(cfg, tasks, results, in_name, out_name):
         item = tasks.get()
         if item is None:
             return
-        pid, q_in, q_out, match_kw = item
+        seq, pid, q_in, q_out, match_kw = item
         raw, _ = slots_in.view(q_in, (K, H, W), np.dtype(cfg["raw_dtype"]))
         refnum = nearest_reference(pid, cfg["ref_nums"]) if cfg["ref_nums"] is not None else 0
         sam = raw.astype(np.float64)
@@ -259,7 +279,7 @@ def _cpu_worker(cfg, tasks, results, in_name, out_name):
             vals[n] = res[k]
         e, off = slots_out.view(q_out, (N0, N1), np.int32, off)
         e[...] = res["err"]
-        results.put(("done", pid, q_in, q_out, None))
+        results.put(("done", seq, q_in, q_out, None))
 
 
 class ProjectionFarm:
@@ -300,7 +320,8 @@ class ProjectionFarm:
                                           args=(d, cfg, w["tasks"], self._results, w["slots_in"].name, w["slots_out"].name))
             w["proc"].start()
             self._workers.append(w)
-        self._by_pid = {}
+        self._by_seq = {}                                           # in flight: internal sequence number -> (worker, caller's id)
+        self._seq = 0
         self._alive = len(self._workers)
 
     # -- submission
@@ -319,11 +340,19 @@ class ProjectionFarm:
         return (w, q), arr
 
     def submit(self, pid, handle, **match_kw):
+        """Queue the projection in input slot ``handle`` under the caller's id ``pid`` (ids may repeat).  The result slots
+        hold full-extent maps: ``ROI`` / ``step`` are not accepted here (match a sub-region with a model of your own)."""
+        bad = [k for k in match_kw if k in ("ROI", "step")]
+        if bad:
+            w, q_in = handle
+            w["free_in"].append(q_in)
+            raise ValueError("ProjectionFarm results are full-extent maps: %s is not supported" % ", ".join(bad))
         w, q_in = handle
         q_out = w["free_out"].pop()
         w["inflight"] += 1
-        self._by_pid[pid] = w
-        w["tasks"].put((pid, q_in, q_out, match_kw))
+        self._seq += 1
+        self._by_seq[self._seq] = (w, pid)
+        w["tasks"].put((self._seq, pid, q_in, q_out, match_kw))
 
     # -- collection
     def _collect(self, timeout):
@@ -347,8 +376,12 @@ class ProjectionFarm:
                 continue
             if kind == "error":
                 raise RuntimeError("farm worker failed: %s" % err)
-            w = self._by_pid.pop(pid)
+            w, pid = self._by_seq.pop(pid)                          # (the second field of a "done" message is the sequence number)
             w["free_in"].append(q_in)
+            if err is not None:                                     # this projection failed in its worker; the farm goes on
+                w["free_out"].append(q_out)
+                w["inflight"] -= 1
+                raise RuntimeError("projection %r failed in the farm worker for device %r: %s" % (pid, w["device"], err))
             off = 0
             res = {}
             for key, shape, dtype in _result_layout(self.N0, self.N1, self.df):
@@ -362,6 +395,22 @@ class ProjectionFarm:
                 w["free_out"].append(q_out)
                 w["inflight"] -= 1
             return pid, res, release
+
+    def _raise_if_dead(self, timeout):
+        """Called when no input slot can be had and nothing is in flight: drain the workers' messages (raising on 'error'
+        and once every worker has exited); blocks for at most a second."""
+        try:
+            kind, _a, _b, _c, err = self._results.get(timeout=1.0)
+        except _queue.Empty:
+            if not any(w["proc"].is_alive() for w in self._workers):
+                raise RuntimeError("all farm workers have exited")
+            return
+        if kind == "error":
+            raise RuntimeError("farm worker failed: %s" % err)
+        if kind == "exit":
+            self._alive -= 1
+            if self._alive <= 0:
+                raise RuntimeError("all farm workers have exited")
 
     def map(self, projections, timeout=600.0, **match_kw):
         """Yield ``(id, result dict)`` as projections complete (not in submission order).  Convenience form: every
@@ -386,6 +435,11 @@ class ProjectionFarm:
                 arr[...] = sam
                 self.submit(pid, handle, **match_kw)
                 inflight += 1
+            if not inflight and not exhausted:
+                # no free slot although nothing is in flight: no worker is alive (each posts 'error' / 'exit' when it
+                # dies, e.g. in its constructor): surface that instead of spinning
+                self._raise_if_dead(timeout)
+                continue
             if inflight:
                 pid, res, release = self._collect(timeout)
                 out = {k: np.array(v) for k, v in res.items()}
@@ -418,11 +472,13 @@ class ProjectionFarm:
 # ------------------------------------------------------------------------------------------------
 # bench.py --config C5
 # ------------------------------------------------------------------------------------------------
-def bench_c5(device=0, steps=1, warmup=1, n_proj=32, raw_dtype=np.uint16):
+def bench_c5(device=0, steps=1, warmup=1, n_proj=32, raw_dtype=np.uint16, keep=None):
     """BASELINE config C5 on one GPU: 32 projections of 2048 x 2048 x 5 frames (Nw=5, max_shift=5, dark-field on) stream
     through one ``StreamingMatcher``: detector counts (uint16) in page-locked host memory -> upload + flat correction ->
     match -> result maps back in page-locked host memory.  A "step" is the whole series; the rate includes every
-    transfer.  Two reference stacks, the nearest one per projection (``umpa_multi.py:133``)."""
+    transfer.  Two reference stacks, the nearest one per projection (``umpa_multi.py:133``).
+    ``keep``: a projection number whose corrected sample stack, reference stack and result maps are handed back beside
+    the JSON line (``(line, extras)``), for the caller's parity check of that projection."""
     from .synth import CONFIGS, make_stack
     cfg = CONFIGS["C5"]
     H, W, K, Nw, ms = cfg["H"], cfg["W"], cfg["K"], cfg["Nw"], cfg["max_shift"]
@@ -449,12 +505,16 @@ def bench_c5(device=0, steps=1, warmup=1, n_proj=32, raw_dtype=np.uint16):
     N0, N1 = sm.model.extent
     ok = 0.0
 
+    kept = {}
+
     def series():
         nonlocal ok
         n, last = 0, None
         for pid, res in sm.run(((p, bufs[p]) for p in range(n_proj))):
             n += 1
             last = res                                              # the consumer of this bench only counts
+            if keep is not None and pid == keep:
+                kept["res"] = {k: np.array(v) for k, v in res.items() if isinstance(v, np.ndarray)}
         ok = float(last["err"].mean())
         return n
 
@@ -467,7 +527,7 @@ def bench_c5(device=0, steps=1, warmup=1, n_proj=32, raw_dtype=np.uint16):
     assert done == n_proj
     in_bytes = K * H * W * np.dtype(raw_dtype).itemsize
     out_bytes = N0 * N1 * (5 * 8 + 4)
-    return {
+    line = {
         "metric": "Mpixels/s (output map) at Nw=%d, max_shift=%d, %d frames" % (Nw, ms, K),
         "value": round(n_proj * N0 * N1 / dt / 1e6, 3), "unit": "Mpx/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -481,3 +541,10 @@ def bench_c5(device=0, steps=1, warmup=1, n_proj=32, raw_dtype=np.uint16):
                    "input_generation_s": round(t_gen, 1)},
         "roofline": None, "cpu_baseline": None,
     }
+    if keep is None:
+        return line
+    refnum = nearest_reference(keep, ref_nums)
+    kept["sam"] = (bufs[keep].astype(np.float64) - dark) / flats[refnum]      # what umpa_multi.py:144 matches
+    kept["ref"] = refs[refnum]
+    kept["Nw"], kept["ms"] = Nw, ms
+    return line, kept
