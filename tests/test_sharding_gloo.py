@@ -357,8 +357,8 @@ def test_projection_farm_two_workers_on_one_gpu(port_ns):
     from umpa_amd.farm import ProjectionFarm
     from umpa_amd.synth import make_stack
     Nw, ms, K, n = 3, 4, 4, 160
-    sam0, ref, _ = make_stack(n, n + 24, K, ms, df=True, seed=60, amplitude=1.5)
-    sams = {p: np.ascontiguousarray(np.roll(sam0, p, axis=2)) for p in range(5)}        # the sample moves a pixel per projection
+    sam0, ref, _ = make_stack(n, n + 24, K, ms, df=True, seed=60, amplitude=1.0)
+    sams = {p: np.ascontiguousarray(np.roll(sam0, p % 2, axis=2)) for p in range(5)}    # two different sample stacks in turn
     with ProjectionFarm(ref, Nw, ms, devices=[0, 0]) as farm:
         res = dict(farm.map(sams.items()))
         assert len(farm._workers) == 2

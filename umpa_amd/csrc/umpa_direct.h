@@ -44,6 +44,7 @@ struct RegionArgs {
     double* kern; size_t kern_stride;   // DFKernel only: per-pixel 17x17 blur kernels, [tap][pixel]
     int row_base;                       // first region row covered by `kern` (row chunking of DFKernel launches)
     double* blur; int blur_F;           // DFKernel only: per-pixel blurred reference footprints, [frame][F][F][pixel] (stride = kern_stride)
+    int blur_ready;                     // DFKernel only: kernels and footprints have been filled by blur_tiles_kernel
 };
 
 // descriptor k, read through the CONSTANT address space: the table is written before any kernel runs and k is
@@ -157,6 +158,112 @@ __device__ inline void blur_footprint(const ModelDev& m, int i, int j, const UMP
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// blur_tiles: blur_footprint for a whole 64 x 4 pixel box at a time ("ideal for LDS tiling").
+//
+// The work of the kernel-dark-field model is this blur: 289 taps x F x F footprint values x Na frames per PIXEL
+// (every pixel has its own kernel, Model.cpp:88-117), 70 k FMAs per pixel on the E_dfkernel-type stack, ~1 M with
+// BASELINE config C2's parameters.  blur_footprint fed them from global memory, 3.3 FMAs per load.  Here the workgroup
+// stages the reference patch of its box (box + halo + 8 on every side; the mask patch beside it) in LDS once per frame;
+// a lane then blurs its footprint in blocks of 4 rows x 8 columns: per kernel row its 17 taps (its own column of the
+// scratch array, coalesced across the wave) and 4 x 24 patch values out of LDS feed 4 x 8 x 17 FMAs -- 32 FMAs per
+// global load, 5.7 per LDS read.  Every output still sums its taps in blur_at's order (kernel rows outer, columns
+// inner), so the footprints -- and every map -- are those of blur_footprint bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define UMPA_BLURT_BX 64
+#define UMPA_BLURT_BY 4
+#define UMPA_BLURT_CH 4               // footprint rows per register block
+#define UMPA_BLURT_CW 8               // footprint columns per register block
+
+struct BlurTileGeom { int halo, F, PR, PC; };     // patch: PR rows of PC doubles (PC includes UMPA_BLURT_CW columns of slack)
+
+inline BlurTileGeom blur_tile_geometry(int halo, int step0, int step1)
+{
+    BlurTileGeom g;
+    g.halo = halo; g.F = 2 * halo + 1;
+    const int reach = halo + UMPA_BLUR_HALF;
+    g.PR = (UMPA_BLURT_BY - 1) * step0 + 1 + 2 * reach + UMPA_BLURT_CH;          // + slack for the last row block
+    g.PC = ((UMPA_BLURT_BX - 1) * step1 + 1 + 2 * reach + UMPA_BLURT_CW) | 1;    // odd pitch
+    return g;
+}
+
+template <bool MASK>
+__global__ void __launch_bounds__(UMPA_BLURT_BX * UMPA_BLURT_BY, 2)
+blur_tiles_kernel(ModelDev m, RegionArgs A, BlurTileGeom G)
+{
+    extern __shared__ __attribute__((aligned(16))) char blur_raw[];
+    double* pimg = reinterpret_cast<double*>(blur_raw);
+    double* pwgt = pimg + G.PR * G.PC;                                 // MASK only
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * UMPA_BLURT_BX + tx;
+    const int xj = blockIdx.x * UMPA_BLURT_BX + tx, xi = blockIdx.y * UMPA_BLURT_BY + ty;
+    const bool valid = xi < A.N0 && xj < A.N1;
+    const size_t px = (size_t)min(xi, A.N0 - 1) * A.N1 + min(xj, A.N1 - 1);
+    const bool wanted = valid && !(A.cover && gp(A.cover)[px] < A.thr);          // model.pyx:480-481
+    const int i = A.org0 + A.step0 * xi, j = A.org1 + A.step1 * xj;
+    const int gi0 = A.org0 + A.step0 * (blockIdx.y * UMPA_BLURT_BY), gj0 = A.org1 + A.step1 * (blockIdx.x * UMPA_BLURT_BX);   // box origin
+    const int reach = G.halo + UMPA_BLUR_HALF, pad = m.padding, F = G.F;
+    const size_t stride = A.kern_stride;
+    UMPA_GLOBAL double* kern = gpw(A.kern) + ((size_t)(min(xi, A.N0 - 1) - A.row_base) * A.N1 + min(xj, A.N1 - 1));
+    UMPA_GLOBAL double* blur = gpw(A.blur) + ((size_t)(min(xi, A.N0 - 1) - A.row_base) * A.N1 + min(xj, A.N1 - 1));
+    if (wanted) {                                                      // Model.cpp:1228-1229: kernel from values[4..6]
+        const UMPA_GLOBAL double* v = gp(A.values) + px * A.v_px;
+        build_blur_kernel(kern, stride, v[4 * A.v_k], v[5 * A.v_k], v[6 * A.v_k]);
+    }
+    for (int k = 0; k < m.Na; k++) {
+        const FrameDesc f = load_frame(m.frames, k);
+        __syncthreads();                                               // the previous frame's patch has been read
+        // ---- stage the patch: image rows gi0 - reach .. of frame k (frame coordinates = image - position), clamped at
+        // the frame edges (what is clamped is never read by a pixel the frame contributes to)
+        for (int q = tid; q < G.PR * G.PC; q += UMPA_BLURT_BX * UMPA_BLURT_BY) {
+            const int r = q / G.PC, c = q - r * G.PC;
+            const size_t src = (size_t)min(max(gi0 - f.pi - reach + r, 0), f.H - 1) * f.W + min(max(gj0 - f.pj - reach + c, 0), f.W - 1);
+            pimg[q] = gp(f.ref)[src];
+            if (MASK) pwgt[q] = gp(f.mask)[src];
+        }
+        __syncthreads();
+        const int li = i - f.pi, lj = j - f.pj;
+        if (!wanted || li - pad < 0 || li + pad > f.H || lj - pad < 0 || lj + pad > f.W) continue;   // frame does not contribute here
+        UMPA_GLOBAL double* out = blur + (size_t)k * F * F * stride;
+        // this pixel's footprint origin inside the patch: footprint (fy, fx), tap (a, b) reads patch (r0 + fy + a, c0 + fx + b)
+        const int r0 = ty * A.step0, c0 = tx * A.step1;
+        for (int fy0 = 0; fy0 < F; fy0 += UMPA_BLURT_CH) {
+            for (int fx0 = 0; fx0 < F; fx0 += UMPA_BLURT_CW) {
+                double acc[UMPA_BLURT_CH][UMPA_BLURT_CW], wacc[MASK ? UMPA_BLURT_CH : 1][UMPA_BLURT_CW];
+#pragma unroll
+                for (int y = 0; y < UMPA_BLURT_CH; y++)
+#pragma unroll
+                    for (int o = 0; o < UMPA_BLURT_CW; o++) { acc[y][o] = 0.0; if (MASK) wacc[y][o] = 0.0; }
+                for (int a = 0; a < UMPA_BLUR_SIDE; a++) {
+                    double kv[UMPA_BLUR_SIDE];
+#pragma unroll
+                    for (int b = 0; b < UMPA_BLUR_SIDE; b++) kv[b] = kern[(size_t)(a * UMPA_BLUR_SIDE + b) * stride];
+#pragma unroll
+                    for (int y = 0; y < UMPA_BLURT_CH; y++) {
+                        const double* row = pimg + (r0 + fy0 + y + a) * G.PC + c0 + fx0;
+                        const double* wrow = pwgt + (r0 + fy0 + y + a) * G.PC + c0 + fx0;
+                        double v[UMPA_BLURT_CW + UMPA_BLUR_SIDE - 1], wv[MASK ? UMPA_BLURT_CW + UMPA_BLUR_SIDE - 1 : 1];
+#pragma unroll
+                        for (int t = 0; t < UMPA_BLURT_CW + UMPA_BLUR_SIDE - 1; t++) { v[t] = row[t]; if (MASK) wv[t] = wrow[t]; }
+#pragma unroll
+                        for (int o = 0; o < UMPA_BLURT_CW; o++)
+#pragma unroll
+                            for (int b = 0; b < UMPA_BLUR_SIDE; b++) {
+                                if (MASK) { acc[y][o] += kv[b] * v[o + b] * wv[o + b]; wacc[y][o] += kv[b] * wv[o + b]; }
+                                else acc[y][o] += kv[b] * v[o + b];
+                            }
+                    }
+                }
+#pragma unroll
+                for (int y = 0; y < UMPA_BLURT_CH; y++)
+#pragma unroll
+                    for (int o = 0; o < UMPA_BLURT_CW; o++)
+                        if (fy0 + y < F && fx0 + o < F)
+                            out[(size_t)((fy0 + y) * F + fx0 + o) * stride] = MASK ? acc[y][o] / wacc[y][o] : acc[y][o];
+            }
+        }
+    }
+}
+
 // One cost evaluation at pixel (i,j), shift (si rows, sj cols).  KIND: 0 NoDF, 1 DF, 2 DFKernel
 // (NoDF arithmetic on a reference blurred on the fly, Model.cpp:997-1151).
 // NWC > 0: the window half-width is a compile-time constant (the column loop unrolls, all loads of a window row are
@@ -232,6 +339,22 @@ __device__ __forceinline__ int eval_direct(const ModelDev& m, int i, int j, int 
                 } else {
                     for (; b + 1 < S; b += 2) pair_step(b);
                 }
+            }
+            if (KIND == 2 && blur && NWC > 0) {
+                // a window row of the pixel's blurred footprint (blur_tiles / blur_footprint: rows / columns relative to
+                // (i, j) - halo): all its loads issued before the first term, the terms summed in the reference's order
+                const int halo = (blur_F - 1) >> 1;
+                const UMPA_GLOBAL double* brow = blur + ((size_t)k * blur_F * blur_F + (size_t)(ri - i + halo - Nw + a) * blur_F + (rj - j + halo - Nw)) * kstride;
+                double rv[2 * NWC + 1], qv[2 * NWC + 1], mrv[MASK ? 2 * NWC + 1 : 1], mqv[MASK ? 2 * NWC + 1 : 1];
+#pragma unroll
+                for (int c = 0; c < 2 * NWC + 1; c++) {
+                    rv[c] = brow[(size_t)c * kstride];
+                    qv[c] = Q[off + c];
+                    if (MASK) { mrv[c] = MR[off + c]; mqv[c] = MQ[off + c]; }
+                }
+#pragma unroll
+                for (int c = 0; c < 2 * NWC + 1; c++) term(wrow[c], rv[c], qv[c], MASK ? mrv[c] : 0.0, MASK ? mqv[c] : 0.0);
+                b = S;
             }
             for (; b < S; b++) {
                 double r;
@@ -317,13 +440,15 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
     UMPA_GLOBAL double* kern = nullptr;
     if (KIND == 2) {                                     // Model.cpp:1228-1229: kernel from values[4..6]
         kern = gpw(A.kern) + ((size_t)(xi - A.row_base) * A.N1 + xj);
-        const UMPA_GLOBAL double* v = gp(A.values) + px * A.v_px;
-        build_blur_kernel(kern, A.kern_stride, v[4 * A.v_k], v[5 * A.v_k], v[6 * A.v_k]);
+        if (!A.blur_ready) {
+            const UMPA_GLOBAL double* v = gp(A.values) + px * A.v_px;
+            build_blur_kernel(kern, A.kern_stride, v[4 * A.v_k], v[5 * A.v_k], v[6 * A.v_k]);
+        }
     }
     UMPA_GLOBAL double* blur = nullptr;
     if (KIND == 2 && A.blur) {                           // the blurred reference this pixel can ever read, once
         blur = gpw(A.blur) + ((size_t)(xi - A.row_base) * A.N1 + xj);
-        blur_footprint<MASK>(m, i, j, kern, A.kern_stride, blur, A.blur_F, (A.blur_F - 1) >> 1);
+        if (!A.blur_ready) blur_footprint<MASK>(m, i, j, kern, A.kern_stride, blur, A.blur_F, (A.blur_F - 1) >> 1);
     }
     Walk w;
     walk_begin(w, memo, A.uv ? gp(A.uv)[2 * px] : 0.0, A.uv ? gp(A.uv)[2 * px + 1] : 0.0);

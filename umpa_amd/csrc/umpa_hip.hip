@@ -113,8 +113,8 @@ struct umpa_hip_model {
 
 namespace {
 
-const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk", "match_staged", "corr_masked", "replay_cost"};
-enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4, KN_STAGED = 5, KN_MASKED = 6, KN_REPLAY_COST = 7 };
+const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk", "match_staged", "corr_masked", "replay_cost", "blur_tiles"};
+enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4, KN_STAGED = 5, KN_MASKED = 6, KN_REPLAY_COST = 7, KN_BLUR = 8 };
 
 hipEvent_t get_event(umpa_hip_model* m)
 {
@@ -190,8 +190,8 @@ void launch_direct_nw(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
 template <int KIND, bool MASK>
 void launch_direct(umpa_hip_model* m, const RegionArgs& A, hipStream_t s)
 {
-    if constexpr (KIND != 2) {
-        switch (m->Nw) {
+    {                                                                 // (the kernel-dark-field model too: its evaluations read the pixel's
+        switch (m->Nw) {                                                // blurred footprint a window row at a time, all loads of a row in flight)
         case 1: return launch_direct_nw<KIND, MASK, 1>(m, A, s);
         case 2: return launch_direct_nw<KIND, MASK, 2>(m, A, s);
         case 3: return launch_direct_nw<KIND, MASK, 3>(m, A, s);
@@ -271,7 +271,7 @@ hipError_t launch_staged(umpa_hip_model* m, const RegionArgs& A, const StagedGeo
 int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags = 0)
 {
     RegionArgs A = A0;
-    A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0;
+    A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0; A.blur_ready = 0;
     // the staged kernel (windows out of LDS) for regions of more than a few pixels whose footprints fit; the plain one
     // (windows through L1) for the kernel-dark-field model, single pixels, large steps, or on request
     static const bool no_staged = getenv("UMPA_HIP_NO_STAGED") != nullptr;
@@ -316,6 +316,33 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
             C.kern = (double*)m->b_kern.p; C.kern_stride = (size_t)C.N0 * C.N1; C.row_base = 0;
             C.blur = no_reuse ? nullptr : C.kern + (size_t)UMPA_BLUR_TAPS * C.kern_stride;
             C.blur_F = F;
+            C.blur_ready = 0;
+            // the footprints of a 64 x 4 pixel box at a time, reference patch staged in LDS (blur_tiles_kernel); where the
+            // patch does not fit (large steps) or on request (UMPA_HIP_DFK_NO_TILES) each lane fills its own as before
+            static const bool no_tiles = getenv("UMPA_HIP_DFK_NO_TILES") != nullptr;
+            const BlurTileGeom BG = blur_tile_geometry(halo, C.step0, C.step1);
+            const size_t blur_lds = (size_t)BG.PR * BG.PC * sizeof(double) * (m->has_mask ? 2 : 1);
+            if (!no_reuse && !no_tiles && blur_lds <= (size_t)UMPA_LDS_BUDGET / 2) {
+                static bool battr[2][64] = {};
+                {
+                    std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+                    if (!battr[m->has_mask][m->device & 63]) {
+                        hipError_t be = m->has_mask
+                            ? hipFuncSetAttribute(reinterpret_cast<const void*>(&blur_tiles_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, UMPA_LDS_BUDGET / 2)
+                            : hipFuncSetAttribute(reinterpret_cast<const void*>(&blur_tiles_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, UMPA_LDS_BUDGET / 2);
+                        if (be != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "blur_tiles attribute: %s", hipGetErrorString(be));
+                        battr[m->has_mask][m->device & 63] = true;
+                    }
+                }
+                dim3 bgrid((C.N1 + UMPA_BLURT_BX - 1) / UMPA_BLURT_BX, (C.N0 + UMPA_BLURT_BY - 1) / UMPA_BLURT_BY), bblk(UMPA_BLURT_BX, UMPA_BLURT_BY);
+                {
+                    ScopedTimer t(m, s, KN_BLUR);
+                    if (m->has_mask) hipLaunchKernelGGL((blur_tiles_kernel<true>), bgrid, bblk, blur_lds, s, m->dev(), C, BG);
+                    else hipLaunchKernelGGL((blur_tiles_kernel<false>), bgrid, bblk, blur_lds, s, m->dev(), C, BG);
+                }
+                HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
+                C.blur_ready = 1;
+            }
             if (m->has_mask) launch_direct<2, true>(m, C, s); else launch_direct<2, false>(m, C, s);
             HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
         }
@@ -846,7 +873,7 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
     RegionArgs A;
     A.org0 = m->padding + start0; A.step0 = step0; A.N0 = N0;       // model.pyx:482-483
     A.org1 = m->padding + start1; A.step1 = step1; A.N1 = N1;
-    A.nparam = nparam; A.thr = cover_threshold; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0;
+    A.nparam = nparam; A.thr = cover_threshold; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0; A.blur_ready = 0;
     const bool planar = (flags & UMPA_HIP_F_PLANAR) != 0;
     A.v_px = planar ? 1 : (size_t)nparam; A.v_k = planar ? n : 1;
 
@@ -962,7 +989,7 @@ int umpa_hip_min(umpa_hip_model* m, int i, int j, double* values, double* uv, do
     RegionArgs A;
     A.org0 = i; A.step0 = 1; A.N0 = 1; A.org1 = j; A.step1 = 1; A.N1 = 1;      // Model::min takes absolute coordinates
     A.values = d; A.nparam = np; A.v_px = np; A.v_k = 1; A.uv = d + 8; A.err = (int*)(d + 10); A.cover = nullptr; A.thr = 0.0;
-    A.dbg_n = (int*)(d + 11); A.dbg_d = d + 12; A.dbg_a = d + 37; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0;
+    A.dbg_n = (int*)(d + 11); A.dbg_d = d + 12; A.dbg_a = d + 37; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0; A.blur_ready = 0;
     if (int rc = run_direct(m, A, s)) return rc;
     HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s), UMPA_HIP_E_DEVICE);
     HIP_TRY(hipStreamSynchronize(s), UMPA_HIP_E_DEVICE);
