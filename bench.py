@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default=None, help="N=1: C2 (default), C1, C3, C5; N>1: C4")
+    ap.add_argument("--config", default=None, help="N=1: C2 (default), C1, C3, C5, C2mask / C2maskNoDF (C2's stack with a 95 %% random mask); N>1: C4")
     ap.add_argument("--rows", type=int, default=0, help="override frame height (debugging)")
     ap.add_argument("--cols", type=int, default=0, help="override frame width (debugging)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -112,8 +112,9 @@ def roofline(kernels, steps, abytes, config):
         out.update(bound="fp64_fma", achieved=round(tf, 3), peak=FP64_PEAK_TF, unit="TFLOP/s", frac=round(tf / FP64_PEAK_TF, 5))
         out["fp64_fma"] = dict(fma_per_launch=fma / max(per_step, 1), achieved_tflops=round(tf, 3), peak_tflops=FP64_PEAK_TF,
                                frac=round(tf / FP64_PEAK_TF, 5),
-                               note="FMAs executed by the tiled path's dominant kernel (host count from the launch geometry), "
-                                    "x2 flop, / its HIP-event duration")
+                               note="fp64 issue slots executed by the tiled path's dominant kernel (corr_volume: all FMAs; corr_masked: an "
+                                    "FMA, multiply or add each one slot), counted on the host from the launch geometry and the device's "
+                                    "count of (tile, pass) units it computed, x2 flop, / its HIP-event duration")
     else:
         out.update(bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"])
     return out
@@ -149,7 +150,10 @@ def main():
     config = args.config or "C2"
     if config == "C5":
         return farm_bench(args, local)
-    cfg = dict(CONFIGS[config])
+    masked = config.startswith("C2mask")
+    cfg = dict(CONFIGS["C2" if masked else config])
+    if config == "C2maskNoDF":
+        cfg["df"] = False
     if args.rows:
         cfg["H"] = args.rows
     if args.cols:
@@ -161,7 +165,8 @@ def main():
     sam, ref, _ = make_stack(H, W, K, ms, df=df, seed=0)
     t_gen = time.time() - t_gen
     cls = model.UMPAModelDF if df else model.UMPAModelNoDF
-    m = cls(sam, ref, window_size=Nw, max_shift=ms, device=local)      # H2D happens here, outside the timed region
+    mask = (np.random.default_rng(1).uniform(size=sam.shape) < 0.95).astype(np.float64) if masked else None
+    m = cls(sam, ref, mask_list=mask, window_size=Nw, max_shift=ms, device=local)      # H2D happens here, outside the timed region
     lib, h = m._lib, m._handle
     N0, N1 = m.extent
     npx = N0 * N1
@@ -170,10 +175,15 @@ def main():
     ncalls = torch.zeros((N0, N1), dtype=torch.int32, device=dev)
     flags = _lib.F_DEVICE_IO | {"auto": 0, "direct": _lib.F_FORCE_DIRECT, "tiled": _lib.F_FORCE_TILED}[args.force]
     stream = torch.cuda.current_stream().cuda_stream
+    cover, thr = None, 0.0
+    if masked:                                              # the coverage map and threshold of model.pyx:427-431, resident like the inputs
+        cm = m.coverage()
+        cover, thr = torch.from_numpy(cm).to(dev), .1 * float(cm.max()) / K
 
     def step(with_ncalls=False):
         rc = lib.match_region(h, 0, 1, N0, 0, 1, N1, values.data_ptr(), nparam, None, err.data_ptr(),
-                              None, 0.0, None, None, ncalls.data_ptr() if with_ncalls else None, flags,
+                              cover.data_ptr() if cover is not None else None, thr, None, None,
+                              ncalls.data_ptr() if with_ncalls else None, flags,
                               ctypes.c_void_p(stream))
         lib.check(rc, "match_region")
 
@@ -189,6 +199,8 @@ def main():
     lib.timing_enable(h, 0)
     kernels = collect_kernels(lib, h)
     path = {1: "direct", 2: "tiled", 3: "direct-staged"}.get(lib.last_path(h), "?")
+    if masked and path == "tiled":
+        path = "tiled (corr_masked + replay_cost)"
 
     step(with_ncalls=True)                                  # untimed: evaluation-count statistics of this dataset
     torch.cuda.synchronize()
@@ -200,7 +212,7 @@ def main():
     roof = roofline(kernels, args.steps, algorithmic_bytes(K, H, W, N0, N1, nparam), config)
     cpu = None
     if not args.no_cpu:
-        cpu = cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1)
+        cpu = cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1, mask=mask)
     out = {
         "metric": "Mpixels/s (output map) at Nw=%d, max_shift=%d, %d frames" % (Nw, ms, K),
         "value": round(npx * args.steps / dt / 1e6, 3),
@@ -211,6 +223,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %dx%d, %d frames, Nw=%d, max_shift=%d, dark-field %s" % (
                        config, H, W, K, Nw, ms, "on" if df else "off"),
+                   "mask": "95 % random 0/1 mask per frame (model.pyx:257-262)" if masked else None,
                    "output_pixels_per_gpu": npx, "kernel_path": path,
                    "Ncalls_mean": round(float(nc.mean()), 3), "Ncalls_p99": int(np.percentile(nc, 99)),
                    "err_ok_fraction": round(float(err_h.mean()), 5), "parallelism": "1 GPU",
@@ -497,7 +510,7 @@ def usable_cpus(info):
     return n
 
 
-def cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1, per_run_s=2.5):
+def cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1, per_run_s=2.5, mask=None):
     """The CPU checker (the reference C++ core where oracle/_ref exists) on bounded row samples of the SAME stack:
     a thread sweep with OMP_PROC_BIND=spread / OMP_PLACES=cores on first-touch-parallel copies of the inputs.
     `value` is the best of the sweep, `value_at_reference_default` the reference's default thread count
@@ -520,7 +533,7 @@ def cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1, per_run_s=2.5):
 
     sam_c, ref_c = rehome(sam), rehome(ref)
     cls = ns.UMPAModelDF if df else ns.UMPAModelNoDF
-    cm = cls(sam_c, ref_c, window_size=Nw, max_shift=ms)
+    cm = cls(sam_c, ref_c, mask_list=mask, window_size=Nw, max_shift=ms)
     cm.debug = True
 
     def run(rows, threads):

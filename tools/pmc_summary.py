@@ -5,7 +5,8 @@ from collections import defaultdict
 
 def short(name):
     n = name.split("(")[0]
-    for key in ("prep_maps", "corr_volume", "replay_walk", "match_direct", "coverage", "cost_one", "spfit"):
+    for key in ("prep_maps", "corr_volume_queue", "corr_volume", "replay_walk", "corr_masked_queue", "corr_masked", "replay_cost",
+                "blur_tiles", "od_list", "match_direct", "match_staged", "coverage", "cost_one", "spfit"):
         if key in n:
             return key
     return n[:60]

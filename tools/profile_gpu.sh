@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repository root:
-#   bash tools/profile_gpu.sh [extra bench.py args]
-# Writes gpurun_out/prof/{stats,pmc*}/ and gpurun_out/prof/summary.json (tools/pmc_summary.py).
+#   [PROF_TAG=name] bash tools/profile_gpu.sh [extra bench.py args]
+# Writes gpurun_out/prof[_name]/{stats,pmc*}/ and gpurun_out/prof[_name]/summary.json (tools/pmc_summary.py).
 # rocprofv3 gets the program itself after `--` (no env/bash wrappers), counters in their own passes.
 set -e
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof
+OUT=$ROOT/gpurun_out/prof${PROF_TAG:+_$PROF_TAG}
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS="--no-cpu --steps 5 --warmup 2 $*"

@@ -66,6 +66,7 @@ struct umpa_hip_model {
     int kind = 0, Na = 0, Nw = 0, ms = 0, padding = 0, subpx = -1, ref_mode = 0, call_cap = UMPA_CALL_CAP;
     int device = 0;
     bool has_mask = false, owns_frames = true;
+    bool mask_binary = false;                      // every mask value is 0 or 1 (corr_masked's cheap pair weight)
     std::vector<int> dims, pos;
     std::vector<double*> d_sam, d_ref, d_mask;     // device frame pointers
     void* d_frames_blob = nullptr;                 // one allocation holding all owned frames
@@ -417,7 +418,7 @@ int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int fla
     tt.get = [m]() { return get_event(m); };
     int rc = m->has_mask
         ? tiled_match_masked(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
-                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows)
+                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, m->mask_binary, piece_rows, on_rows)
         : tiled_match(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
                       m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
     if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
@@ -635,6 +636,22 @@ umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const
         if (!ok) fail(UMPA_HIP_E_NOMEM, "cannot allocate the frame descriptor table");
     }
     if (ok) ok = upload_win(m, win, Nw) == 0;
+    if (ok && m->has_mask && m->owns_frames && !getenv("UMPA_HIP_NO_BINARY_MASKS")) {
+        // 0/1 masks let corr_masked form the pair weight with one multiply; owned frames only (borrowed ones may change)
+        int* d_flag = nullptr;
+        int h_flag = 1;
+        size_t total = 0;
+        for (int k = 0; k < Na; k++) total += (size_t)dims[2 * k] * dims[2 * k + 1];
+        if (hipMalloc((void**)&d_flag, sizeof(int)) == hipSuccess) {
+            if (hipMemcpy(d_flag, &h_flag, sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
+                hipLaunchKernelGGL(umpa::mask_binary_kernel, dim3(2048), dim3(256), 0, m->stream, (const double*)m->d_mask[0], total, d_flag);
+                if (hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+                    hipStreamSynchronize(m->stream) != hipSuccess) h_flag = 0;
+                m->mask_binary = h_flag == 1;
+            }
+            (void)hipFree(d_flag);
+        }
+    }
     if (!ok) { umpa_hip_destroy(m); return nullptr; }
     return m;
 }

@@ -39,6 +39,7 @@ struct MaskedArgs {
     int sigma;                // +1 'sam' mode: A = sample at p, B = reference at p+u; -1 'ref' mode: A = reference at p, B = sample at p-u
     int ntx, nty;
     int br0, br1, bc0, bc1, Wf;
+    int binary;               // every mask value is 0 or 1 (checked on the device when the model is created): pw(a, b) = a b / (2 + 1e-8)
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE_MASKED): 1 means = 1, 2 weight = mask product, 4 no column filter, 8 no row filter
 };
 
@@ -81,6 +82,18 @@ struct MaskCfg {
     static constexpr int VITEMS = 4 * (TR / CB) * TC;                           // = NT: one item per thread (DF: the fourth set is plane w again)
     static constexpr bool OK = QR * NQB <= NT && LDS <= (size_t)UMPA_LDS_BUDGET && VITEMS == NT && NPT <= 16;
 };
+
+// all values of a mask stack 0 or 1?  (*flag starts at 1)
+__global__ void __launch_bounds__(256)
+mask_binary_kernel(const double* __restrict__ mask, size_t n, int* flag)
+{
+    bool ok = true;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+        const double v = gp(mask)[q];
+        ok = ok && (v == 0.0 || v == 1.0);
+    }
+    if (!ok) *flag = 0;
+}
 
 // combine_weights (Utils.cpp:125-130) with v_rcp_f64 and ONE Newton step (relative error ~1e-14; the weight enters
 // every sum linearly and identically, so this is a 1e-14 perturbation of the window, not of a cancellation)
@@ -271,7 +284,9 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
                 const int tb = t + (u & 1);
                 const double a = av[t >> 1][t & 1], ma = mav[t >> 1][t & 1];
                 const double b = bv[tb >> 1][tb & 1], mb = mbv[tb >> 1][tb & 1];
-                const double w = (A.ablate & 2) ? ma * mb : pair_weight_fast(mb, ma);
+                // 0/1 masks (the usual bad-pixel masks): a b / (a + b + 1e-8) is 0 or 1 / (2 + 1e-8) -- one multiply instead of
+                // a reciprocal and a Newton step, the same number to the last bits
+                const double w = A.binary ? ma * mb * (1.0 / (2.0 + 1e-8)) : (A.ablate & 2) ? ma * mb : pair_weight_fast(mb, ma);
                 const double wa = w * a, wb = w * b;
                 PAA[t][u] = fma(wa, a, PAA[t][u]);
                 PBB[t][u] = fma(wb, b, PBB[t][u]);

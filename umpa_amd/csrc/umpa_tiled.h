@@ -1010,7 +1010,7 @@ inline hipError_t launch_masked(const ModelDev& dev, MaskedArgs A, const Sep1D& 
 
 // One match of a region of a masked model.  Returns 0, -3 (allocation) or a positive hipError_t.
 inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int H, int W, const FrameBox& box, const RegionArgs& A,
-                              hipStream_t s, TiledTimers* tt, bool reuse_ref_maps,
+                              hipStream_t s, TiledTimers* tt, bool reuse_ref_maps, bool binary_masks,
                               int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
 {
     const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1, NV = kind == 1 ? 3 : 2;
@@ -1101,6 +1101,7 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
         MA.sigma = dev.ref_mode ? -1 : 1;
         MA.br0 = box.r0; MA.br1 = box.r1; MA.bc0 = box.c0; MA.bc1 = box.c1; MA.Wf = box.Wf;
         MA.ntx = MA.nty = 0;
+        MA.binary = binary_masks ? 1 : 0;
         { const char* ab = getenv("UMPA_HIP_ABLATE_MASKED"); MA.ablate = ab ? atoi(ab) : 0; }
         const int xi_lo = (drow0 + A.step0 - 1) / A.step0;
         const int xi_hi = std::min(A.N0, (drow0 + drows - 1) / A.step0 + 1);
