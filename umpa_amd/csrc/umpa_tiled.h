@@ -306,10 +306,14 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
 #endif
 #define UMPA_REPLAY_THREADS (64 * UMPA_REPLAY_ROWS)
 
-template <int KIND, int NA>
+// OD = false: the plain kernel (every table plane is there): the on-demand bookkeeping compiles away (it costs 20 VGPRs and
+// 0.1 ms on C2 otherwise)
+template <int KIND, int NA, bool OD>
 __global__ void __launch_bounds__(UMPA_REPLAY_THREADS, 3)
-replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od)
+replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
 {
+    OdArgs od = od_in;
+    if (!OD) od.mode = 0;
     __shared__ double memo_lds[25 * UMPA_REPLAY_THREADS];
     const LdsMemo<UMPA_REPLAY_THREADS> memo = {memo_lds + threadIdx.y * 64 + threadIdx.x};
     // od.mode (umpa_ondemand.h): 0 every pixel, every table plane is there; 1 the pixels of the seed tiles (a compact grid;
@@ -895,7 +899,8 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
             if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);   // queue over the parked pixels
             if (od.mode == 1) { blk = dim3(64, 1); grd = dim3((32 * od.tc + 63) / 64, od_seed_count(od.ntx, od.c0) * od_seed_count(od.nty, od.r0)); if (!grd.y) return hipSuccess; }
             tic(4);
-#define UMPA_REPLAY_NA(n) case n: hipLaunchKernelGGL((replay_walk_kernel<1, n>), grd, blk, 0, s, dev, M, R, A, od); break;
+#define UMPA_REPLAY_NA(n) case n: if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<1, n, true>), grd, blk, 0, s, dev, M, R, A, od); \
+                           else hipLaunchKernelGGL((replay_walk_kernel<1, n, false>), grd, blk, 0, s, dev, M, R, A, od); break;
             if (kind == 1 && small && dev.Na <= UMPA_KTEMPL) {
                 switch (dev.Na) {
                     UMPA_REPLAY_NA(1) UMPA_REPLAY_NA(2) UMPA_REPLAY_NA(3) UMPA_REPLAY_NA(4) UMPA_REPLAY_NA(5) UMPA_REPLAY_NA(6)
@@ -903,8 +908,11 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
                     UMPA_REPLAY_NA(13) UMPA_REPLAY_NA(14) UMPA_REPLAY_NA(15) UMPA_REPLAY_NA(16) UMPA_REPLAY_NA(17) UMPA_REPLAY_NA(18)
                     UMPA_REPLAY_NA(19) UMPA_REPLAY_NA(20) UMPA_REPLAY_NA(21) UMPA_REPLAY_NA(22) UMPA_REPLAY_NA(23) UMPA_REPLAY_NA(24)
                 }
-            } else if (kind == 1) hipLaunchKernelGGL((replay_walk_kernel<1, 0>), grd, blk, 0, s, dev, M, R, A, od);
-            else hipLaunchKernelGGL((replay_walk_kernel<0, 0>), grd, blk, 0, s, dev, M, R, A, od);
+            } else if (kind == 1) {
+                if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<1, 0, true>), grd, blk, 0, s, dev, M, R, A, od);
+                else hipLaunchKernelGGL((replay_walk_kernel<1, 0, false>), grd, blk, 0, s, dev, M, R, A, od);
+            } else if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<0, 0, true>), grd, blk, 0, s, dev, M, R, A, od);
+            else hipLaunchKernelGGL((replay_walk_kernel<0, 0, false>), grd, blk, 0, s, dev, M, R, A, od);
 #undef UMPA_REPLAY_NA
             toc();
             return hipGetLastError();
