@@ -510,3 +510,31 @@ def test_on_demand_table_passes_change_nothing(hip_ns, monkeypatch, cfg):
     assert stats["0"][0] == stats["0"][1] and stats["0"][2] == 0          # exhaustive: every unit, nothing parked
     assert stats["1"][1] == stats["0"][1] and stats["1"][0] < stats["1"][1], stats   # (harsh fields on small images: few passes go unread)
     assert stats["1"][2] > 0, stats                                       # some walks were parked and run again
+
+
+@pytest.mark.parametrize("df", [True, False])
+def test_masks_and_sample_stepping_together(hip_ns, port_ns, df):
+    """Masks AND frames at different positions: the rectangle every frame contributes to runs on the masked tiled path
+    (frame positions folded into the staging addresses of frames and masks), the border strips on the general kernels
+    (path 4); against the CPU oracle, coverage map (mask-weighted) included."""
+    from umpa_amd.synth import make_stack
+    Nw, ms, K = 3, 4, 5
+    pos = [np.array(p) for p in [(0, 0), (0, 12), (8, 0), (8, 12), (4, 6)]]
+    frames = [make_stack(140, 160, 1, ms, df=df, seed=500 + k, amplitude=2.0) for k in range(K)]
+    sam = [np.ascontiguousarray(f[0][0]) for f in frames]
+    ref = [np.ascontiguousarray(f[1][0]) for f in frames]
+    rng = np.random.default_rng(8)
+    mask = [(rng.random(s.shape) < 0.92).astype(np.float64) for s in sam]
+    name = "UMPAModelDF" if df else "UMPAModelNoDF"
+    kw = dict(window_size=Nw, max_shift=ms, pos_list=pos, mask_list=mask)
+    g, o = getattr(hip_ns, name)(sam, ref, **kw), getattr(port_ns, name)(sam, ref, **kw)
+    got, want = g.match(quiet=True), o.match(quiet=True)
+    assert g._lib.last_path(g._handle) == 4
+    st = assert_parity(got, want, ms, "masks + stepping %s" % name)
+    assert st["ok"] > 1000
+    np.testing.assert_array_equal(g.coverage(), o.coverage())
+    g.ROI = None
+    roi = ((14, 110, 1), (18, 130, 1))                              # inside the fully covered rectangle: the tiled path alone
+    got, want = g.match(ROI=roi, quiet=True), o.match(ROI=roi, quiet=True)
+    assert g._lib.last_path(g._handle) == 2
+    assert_parity(got, want, ms, "masks + stepping ROI %s" % name)
