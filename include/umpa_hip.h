@@ -112,7 +112,10 @@ int umpa_hip_stage_sample(umpa_hip_model *m, const void *const *raw, int raw_dty
 typedef void (*umpa_hip_rows_fn)(int row_lo, int row_hi, void *user);
 int umpa_hip_set_rows_callback(umpa_hip_model *m, umpa_hip_rows_fn fn, void *user, int piece_rows);
 
-/* wait for an UMPA_HIP_F_ASYNC match of this model (kernels and downloads); returns its status */
+/* wait for the OLDEST UMPA_HIP_F_ASYNC match of this model that is still in flight (kernels and downloads); returns its
+ * status.  Up to two may be in flight (the library keeps two sets of device output buffers: the maps of match p travel to
+ * the host while match p + 1 is computed); a third UMPA_HIP_F_ASYNC call, or a synchronous one, before the wait is
+ * UMPA_HIP_E_ARG.  With nothing in flight it waits for the model's streams. */
 int umpa_hip_wait(umpa_hip_model *m);
 /* page-lock / release memory the caller owns (a shared-memory ring that feeds umpa_hip_stage_sample) */
 int umpa_hip_host_register(void *p, size_t bytes);

@@ -86,12 +86,19 @@ struct umpa_hip_model {
     hipEvent_t ev_read_done[2] = {nullptr, nullptr};   // after the last match that read sample buffer 0 (front at creation) / 1
     bool read_once[2] = {false, false};
     bool staged = false;
-    std::vector<hipEvent_t> pending_events;        // of an UMPA_HIP_F_ASYNC match, recycled by umpa_hip_wait
+    // UMPA_HIP_F_ASYNC matches in flight (at most two: each owns one of the two device output sets), oldest first:
+    // the events of its row pieces (recycled by umpa_hip_wait) and `done`, recorded behind its last download
+    struct PendingMatch { std::vector<hipEvent_t> events; hipEvent_t done; };
+    std::vector<PendingMatch> pending;
+    int out_set = 0;                               // device output set of the next host-array match
     umpa_hip_rows_fn rows_cb = nullptr;            // umpa_hip_set_rows_callback: told after the kernels of a row piece are enqueued
     void* rows_user = nullptr;
     int rows_piece_rows = 0;
     FrameDesc* h_desc = nullptr;                   // pinned host copy of the descriptor table (source of the stream-ordered update)
-    DevBuf b_values, b_uv, b_err, b_cover, b_dd, b_da, b_dn, b_small, b_kern;
+    // device copies of a host-array match's arrays, two sets: the maps of match p travel to the host while match p + 1
+    // (the step-scan pipeline, umpa_amd/farm.py) already writes the other set
+    DevBuf b_values[2], b_uv[2], b_err[2], b_cover[2], b_dd[2], b_da[2], b_dn[2];
+    DevBuf b_covout, b_small, b_kern;
     DevBuf t_values, t_uv, t_err, t_cover, t_dd, t_da, t_dn;   // dense outputs of a sub-rectangle (sample-stepping split)
     TiledState tiled;                              // scratch of the tiled fast path
     int last_path = 0;
@@ -736,10 +743,17 @@ int umpa_hip_wait(umpa_hip_model* m)
 {
     if (!m) return fail(UMPA_HIP_E_ARG, "null model");
     HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
+    if (!m->pending.empty()) {                                        // the OLDEST asynchronous match: kernels and downloads
+        umpa_hip_model::PendingMatch pm = m->pending.front();
+        m->pending.erase(m->pending.begin());
+        const hipError_t de = pm.done ? hipEventSynchronize(pm.done) : hipStreamSynchronize(m->copy_stream);
+        for (auto e : pm.events) m->event_pool.push_back(e);
+        if (pm.done) m->event_pool.push_back(pm.done);
+        if (de != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "asynchronous match (kernels or download of the result maps): %s", hipGetErrorString(de));
+        return UMPA_HIP_ST_OK;
+    }
     const hipError_t se = hipStreamSynchronize(m->stream);
     const hipError_t ce = hipStreamSynchronize(m->copy_stream);
-    for (auto e : m->pending_events) m->event_pool.push_back(e);
-    m->pending_events.clear();
     if (se != hipSuccess) return fail(UMPA_HIP_E_LAUNCH, "match kernels: %s", hipGetErrorString(se));
     if (ce != hipSuccess) return fail(UMPA_HIP_E_DEVICE, "download of the result maps: %s", hipGetErrorString(ce));
     return UMPA_HIP_ST_OK;
@@ -768,8 +782,11 @@ void umpa_hip_destroy(umpa_hip_model* m)
     for (auto& l : m->launches) { (void)hipEventDestroy(l.t0); (void)hipEventDestroy(l.t1); }
     for (auto e : m->event_pool) (void)hipEventDestroy(e);
     tiled_release(m->tiled);
-    m->b_values.release(); m->b_uv.release(); m->b_err.release(); m->b_cover.release();
-    m->b_dd.release(); m->b_da.release(); m->b_dn.release(); m->b_small.release(); m->b_kern.release();
+    for (int q = 0; q < 2; q++) {
+        m->b_values[q].release(); m->b_uv[q].release(); m->b_err[q].release(); m->b_cover[q].release();
+        m->b_dd[q].release(); m->b_da[q].release(); m->b_dn[q].release();
+    }
+    m->b_covout.release(); m->b_small.release(); m->b_kern.release();
     m->t_values.release(); m->t_uv.release(); m->t_err.release(); m->t_cover.release(); m->t_dd.release(); m->t_da.release(); m->t_dn.release();
     if (m->d_desc) (void)hipFree(m->d_desc);
     if (m->d_win) (void)hipFree(m->d_win);
@@ -779,7 +796,7 @@ void umpa_hip_destroy(umpa_hip_model* m)
     if (m->h_desc) (void)hipHostFree(m->h_desc);
     if (m->ev_staged) (void)hipEventDestroy(m->ev_staged);
     for (int q = 0; q < 2; q++) if (m->ev_read_done[q]) (void)hipEventDestroy(m->ev_read_done[q]);
-    for (auto e : m->pending_events) (void)hipEventDestroy(e);
+    for (auto& pm : m->pending) { for (auto e : pm.events) (void)hipEventDestroy(e); if (pm.done) (void)hipEventDestroy(pm.done); }
     if (m->up_stream) { (void)hipStreamSynchronize(m->up_stream); (void)hipStreamDestroy(m->up_stream); }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
@@ -820,15 +837,15 @@ int umpa_hip_coverage_region(umpa_hip_model* m, int start0, int step0, int N0, i
     if (int rc = check_region(m, start0, step0, N0, start1, step1, N1)) return rc;
     HIP_TRY(hipSetDevice(m->device), UMPA_HIP_E_DEVICE);
     const size_t n = (size_t)N0 * N1;
-    if (m->b_cover.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "coverage buffer");
+    if (m->b_covout.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "coverage buffer");
     dim3 blk(64, 4), grd((N1 + 63) / 64, (N0 + 3) / 4);
     {
         ScopedTimer t(m, m->stream, KN_COVER);
         hipLaunchKernelGGL(coverage_kernel, grd, blk, 0, m->stream, m->dev(), m->padding + start0, step0, N0,
-                           m->padding + start1, step1, N1, (int)m->has_mask, (double*)m->b_cover.p);
+                           m->padding + start1, step1, N1, (int)m->has_mask, (double*)m->b_covout.p);
     }
     HIP_TRY(hipGetLastError(), UMPA_HIP_E_LAUNCH);
-    HIP_TRY(hipMemcpyAsync(out, m->b_cover.p, n * sizeof(double), hipMemcpyDeviceToHost, m->stream), UMPA_HIP_E_DEVICE);
+    HIP_TRY(hipMemcpyAsync(out, m->b_covout.p, n * sizeof(double), hipMemcpyDeviceToHost, m->stream), UMPA_HIP_E_DEVICE);
     HIP_TRY(hipStreamSynchronize(m->stream), UMPA_HIP_E_DEVICE);
     return UMPA_HIP_ST_OK;
 }
@@ -908,40 +925,46 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
     }
 
     hipStream_t s = m->stream;
+    if ((flags & UMPA_HIP_F_ASYNC) && m->pending.size() >= 2)
+        return fail(UMPA_HIP_E_ARG, "two asynchronous matches are in flight already: umpa_hip_wait() for the older one first");
+    if (!(flags & UMPA_HIP_F_ASYNC) && !m->pending.empty())
+        return fail(UMPA_HIP_E_ARG, "an asynchronous match is in flight: umpa_hip_wait() first");
+    const int os = m->out_set;                                        // this match's device output set
+    m->out_set ^= 1;
     if (int rc = adopt_staged(m, flags, s)) return rc;
-    if (m->b_values.reserve(n * nparam * sizeof(double)) || m->b_err.reserve(n * sizeof(int)))
+    if (m->b_values[os].reserve(n * nparam * sizeof(double)) || m->b_err[os].reserve(n * sizeof(int)))
         return fail(UMPA_HIP_E_NOMEM, "output buffers (%zu pixels)", n);
     // values and err start from the caller's arrays (zeros in the reference, model.pyx:455,468).  They only matter
     // where the kernel reads them (DFKernel's a,b,c) or leaves them alone (pixels skipped by the coverage test):
     // otherwise every element is overwritten and the upload is skipped.
     if (m->kind == UMPA_HIP_KIND_DFKERNEL || covermap) {
-        HIP_TRY(hipMemcpyAsync(m->b_values.p, values, n * nparam * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
-        HIP_TRY(hipMemcpyAsync(m->b_err.p, err, n * sizeof(int), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+        HIP_TRY(hipMemcpyAsync(m->b_values[os].p, values, n * nparam * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+        HIP_TRY(hipMemcpyAsync(m->b_err[os].p, err, n * sizeof(int), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
     }
-    A.values = (double*)m->b_values.p; A.err = (int*)m->b_err.p;
+    A.values = (double*)m->b_values[os].p; A.err = (int*)m->b_err[os].p;
     A.uv = nullptr; A.cover = nullptr; A.dbg_d = nullptr; A.dbg_a = nullptr; A.dbg_n = nullptr;
     if (uv) {
-        if (m->b_uv.reserve(n * 2 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "uv buffer");
-        HIP_TRY(hipMemcpyAsync(m->b_uv.p, uv, n * 2 * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
-        A.uv = (double*)m->b_uv.p;
+        if (m->b_uv[os].reserve(n * 2 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "uv buffer");
+        HIP_TRY(hipMemcpyAsync(m->b_uv[os].p, uv, n * 2 * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+        A.uv = (double*)m->b_uv[os].p;
     }
     if (covermap) {
-        if (m->b_cover.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "coverage buffer");
-        HIP_TRY(hipMemcpyAsync(m->b_cover.p, covermap, n * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
-        A.cover = (const double*)m->b_cover.p;
+        if (m->b_cover[os].reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "coverage buffer");
+        HIP_TRY(hipMemcpyAsync(m->b_cover[os].p, covermap, n * sizeof(double), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+        A.cover = (const double*)m->b_cover[os].p;
     }
     // The debug maps are written for every pixel the kernels visit: they only need clearing where the coverage test
     // may skip pixels (1.4 GB of memset per C2 match otherwise).
     const bool clear_dbg = covermap != nullptr;
-    if (dbg_d) { if (m->b_dd.reserve(n * 25 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_d buffer");
-                 if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_dd.p, 0, n * 25 * sizeof(double), s), UMPA_HIP_E_DEVICE);
-                 A.dbg_d = (double*)m->b_dd.p; }
-    if (dbg_a) { if (m->b_da.reserve(n * 16 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_a buffer");
-                 if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_da.p, 0, n * 16 * sizeof(double), s), UMPA_HIP_E_DEVICE);
-                 A.dbg_a = (double*)m->b_da.p; }
-    if (dbg_ncalls) { if (m->b_dn.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "debug_Ncalls buffer");
-                      if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_dn.p, 0, n * sizeof(int), s), UMPA_HIP_E_DEVICE);
-                      A.dbg_n = (int*)m->b_dn.p; }
+    if (dbg_d) { if (m->b_dd[os].reserve(n * 25 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_d buffer");
+                 if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_dd[os].p, 0, n * 25 * sizeof(double), s), UMPA_HIP_E_DEVICE);
+                 A.dbg_d = (double*)m->b_dd[os].p; }
+    if (dbg_a) { if (m->b_da[os].reserve(n * 16 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "debug_a buffer");
+                 if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_da[os].p, 0, n * 16 * sizeof(double), s), UMPA_HIP_E_DEVICE);
+                 A.dbg_a = (double*)m->b_da[os].p; }
+    if (dbg_ncalls) { if (m->b_dn[os].reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "debug_Ncalls buffer");
+                      if (clear_dbg) HIP_TRY(hipMemsetAsync(m->b_dn[os].p, 0, n * sizeof(int), s), UMPA_HIP_E_DEVICE);
+                      A.dbg_n = (int*)m->b_dn[os].p; }
 
     // The region is matched in a few row chunks; all kernels are enqueued first (each chunk leaves an event on the
     // compute stream), then the rows of chunk c travel to the host on the copy stream while chunk c+1 is still
@@ -979,7 +1002,11 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
         down(dbg_ncalls, A.dbg_n, sizeof(int), 1, p.lo, p.hi);
     }
     if ((flags & UMPA_HIP_F_ASYNC) && ce == hipSuccess) {          // the caller collects the result with umpa_hip_wait
-        for (const Piece& p : piece_list) if (p.done) m->pending_events.push_back(p.done);
+        umpa_hip_model::PendingMatch pm;
+        for (const Piece& p : piece_list) if (p.done) pm.events.push_back(p.done);
+        pm.done = get_event(m);
+        if (pm.done) (void)hipEventRecord(pm.done, cs);              // behind the last download of this match
+        m->pending.push_back(pm);
         return UMPA_HIP_ST_OK;
     }
     if (ce == hipSuccess) ce = hipStreamSynchronize(cs);

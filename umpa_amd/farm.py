@@ -98,24 +98,33 @@ class StreamingMatcher:
             self._refnum = refnum
 
     def run(self, items, **match_kw):
-        """``items`` yields ``(proj_num, raw_stack)``; yields ``(proj_num, result)`` in the same order.  While
-        projection p is matched, projection p+1 is already on its way to the GPU."""
+        """``items`` yields ``(proj_num, raw_stack)``; yields ``(proj_num, result)`` in the same order.  Two matches are
+        in flight: while the maps of projection p travel to the host, projection p+1 is being matched (into the library's
+        other device output set) and projection p+2 is on its way to the GPU."""
+        from collections import deque
         match_kw.setdefault("quiet", True)
         it = iter(items)
-        try:
-            cur = next(it)
-        except StopIteration:
-            return
-        cur_ref = self._stage(*cur)
-        while cur is not None:
-            self._switch_reference(cur_ref)
-            self.model._out_alloc = self.out_alloc
-            res = self.model.match_async(**match_kw)                # adopts the staged stack, enqueues kernels + downloads
-            nxt = next(it, None)
-            nxt_ref = self._stage(*nxt) if nxt is not None else None   # upload p+1 while p is being matched
-            self.model.wait()
-            yield cur[0], res
-            cur, cur_ref = nxt, nxt_ref
+        cur = next(it, None)
+        cur_ref = self._stage(*cur) if cur is not None else None
+        pending = deque()
+        while cur is not None or pending:
+            if cur is not None:
+                if cur_ref != self._refnum:                         # a reference switch needs an idle model: hand out what is in flight
+                    while pending:
+                        pid, res = pending.popleft()
+                        self.model.wait()
+                        yield pid, res
+                self._switch_reference(cur_ref)
+                self.model._out_alloc = self.out_alloc
+                res = self.model.match_async(**match_kw)            # adopts the staged stack, enqueues kernels + downloads
+                pending.append((cur[0], res))
+                nxt = next(it, None)
+                nxt_ref = self._stage(*nxt) if nxt is not None else None   # upload the next one while this one is being matched
+                cur, cur_ref = nxt, nxt_ref
+            if len(pending) == 2 or cur is None:
+                pid, res = pending.popleft()
+                self.model.wait()                                   # the OLDEST match in flight
+                yield pid, res
 
 
 # ------------------------------------------------------------------------------------------------
