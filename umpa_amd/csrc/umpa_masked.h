@@ -43,9 +43,11 @@ struct MaskedArgs {
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE_MASKED): 1 means = 1, 2 weight = mask product, 4 no column filter, 8 no row filter
 };
 
-template <int KIND, int NW, int UB>
+// TC = 32: one 512-thread workgroup per CU; TC = 16: 256 threads on 32 x 16 tiles, two workgroups per CU (their barrier-
+// separated phases overlap each other; 21 % more halo in the products, a quarter more staging per pixel)
+template <int KIND, int NW, int UB, int TC_ = UMPA_TILE>
 struct MaskCfg {
-    static constexpr int NT = 512, TR = UMPA_TILE, TC = UMPA_TILE, S = 2 * NW + 1, NPX = TR * TC;
+    static constexpr int TC = TC_, NT = TC_ == 32 ? 512 : 256, WPC = TC_ == 32 ? 1 : 2, TR = UMPA_TILE, S = 2 * NW + 1, NPX = TR * TC;
     static constexpr int NV = KIND == 1 ? 3 : 2;
     static constexpr int QR = TR + 2 * NW, QC = TC + 2 * NW, QP = QR | 1;
     static constexpr int PPL = QC * QP + ((QR - QC * QP) % 32 + 32) % 32;       // as CorrCfg::PPL
@@ -65,7 +67,7 @@ struct MaskCfg {
     static constexpr int NSUM = KIND == 1 ? 7 : 4;                              // sums that meet in LDS for the solve
     static constexpr int NPL = KIND == 1 ? 3 : 4;                               // planes per filter round
     // NoDF: the planes and the sums are only needed after the last frame and lie over the frame slots
-    static constexpr int NSLOT = (KIND != 1 && 2 * SLOT * 8 <= UMPA_LDS_BUDGET) ? 2 : 1;
+    static constexpr int NSLOT = (KIND != 1 && 2 * SLOT * 8 <= (UMPA_LDS_BUDGET / WPC)) ? 2 : 1;
     static constexpr int RING = NSLOT * SLOT > NSUM * NPX ? NSLOT * SLOT : NSUM * NPX;
     static constexpr int END_NODF = NSUM * NPX + NPL * PPL;
     // DF: the means of a frame pair under the pixels of the tile, widened by the column offsets of the pass:
@@ -74,13 +76,17 @@ struct MaskCfg {
     static constexpr int NMU = (TR * MW + NT - 1) / NT;                         // DMA instructions per thread and frame pair
     static constexpr int MU_DMA = NMU * NT * 2;                                 // doubles one buffer must hold (every lane writes)
     static constexpr int LDS_DF_NOMU = RING + NPL * PPL;
-    static constexpr bool MULDS = KIND == 1 && (size_t)(LDS_DF_NOMU + 2 * MU_DMA) * 8 <= (size_t)UMPA_LDS_BUDGET;
-    static constexpr int LDS_DOUBLES = KIND == 1 ? LDS_DF_NOMU + (MULDS ? 2 * MU_DMA : 0) : (RING > END_NODF ? RING : END_NODF);
+    static constexpr int LDSB = (UMPA_LDS_BUDGET / WPC) & ~15;                  // what one workgroup may use
+    // buffers for the means: 2 (the next pair arrives while this one is read), 1 (it arrives at the head of the even frame
+    // and is waited for before the first row filter), 0 (read from global memory)
+    static constexpr int MUBUFS = KIND != 1 ? 0 : (size_t)(LDS_DF_NOMU + 2 * MU_DMA) * 8 <= (size_t)LDSB ? 2 : (size_t)(LDS_DF_NOMU + MU_DMA) * 8 <= (size_t)LDSB ? 1 : 0;
+    static constexpr bool MULDS = MUBUFS > 0;
+    static constexpr int LDS_DOUBLES = KIND == 1 ? LDS_DF_NOMU + MUBUFS * MU_DMA : (RING > END_NODF ? RING : END_NODF);
     static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
     static constexpr int CB = 8;
     static constexpr int HITEMS = NPL * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
     static constexpr int VITEMS = 4 * (TR / CB) * TC;                           // = NT: one item per thread (DF: the fourth set is plane w again)
-    static constexpr bool OK = QR * NQB <= NT && LDS <= (size_t)UMPA_LDS_BUDGET && VITEMS == NT && NPT <= 16;
+    static constexpr bool OK = QR * NQB <= NT && LDS <= (size_t)LDSB && VITEMS == NT && NPT <= 16;
 };
 
 // all values of a mask stack 0 or 1?  (*flag starts at 1)
@@ -124,11 +130,11 @@ __device__ __forceinline__ void fir_stream(const double* __restrict__ in, int st
 }
 
 // the finished costs of one (tile, pass) into the table
-template <int KIND, int NW, int UB>
+template <int KIND, int NW, int UB, int TCT>
 __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const MaskedArgs& A, const Sep1D& sep, double* ring,
                                                  const int lin, const int pass, const int tid)
 {
-    using C = MaskCfg<KIND, NW, UB>;
+    using C = MaskCfg<KIND, NW, UB, TCT>;
     constexpr int NT = C::NT, QB = C::QB, TC = C::TC, TR = C::TR, NPX = C::NPX;
     double* sums = ring;                                                // after the last frame: [NSUM][NPX]
     double* planes = KIND == 1 ? ring + C::RING : ring + C::NSUM * NPX;  // NoDF: over the slots, after the last frame
@@ -189,9 +195,12 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
             const UMPA_GLOBAL char* src = (sel == 0 ? gA : sel == 2 ? gB : gM) + src_off[n];
             __builtin_amdgcn_global_load_lds(src, slot + (size_t)(wave_piece0 + n * NT) * 16, 16, 0, 0);
         }
-        if (C::MULDS && (k & 1) == 0) {                                 // the means of frames k and k+1
+        // (two buffers for the means: they ride with the even frame; one buffer: see the head of the frame loop)
+    };
+    auto issue_means = [&](int k) {                                     // the means of frames k and k+1 (k even)
+        {
             const UMPA_GLOBAL char* gmu = (const UMPA_GLOBAL char*)gp(A.MR) + (size_t)(k >> 1) * mplane * 16;
-            UMPA_LDS_AS char* dst = (UMPA_LDS_AS char*)(mubuf + ((k >> 1) & 1) * C::MU_DMA);
+            UMPA_LDS_AS char* dst = (UMPA_LDS_AS char*)(mubuf + (C::MUBUFS == 2 ? ((k >> 1) & 1) : 0) * C::MU_DMA);
 #pragma unroll
             for (int n = 0; n < C::NMU; n++) {
                 // (the source through a local: with the subscript inside the builtin's argument list clang drops the kernel's
@@ -262,12 +271,14 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
 
     const int K = m.Na;
     issue_frame(0);
+    if (C::MUBUFS == 2) issue_means(0);
     for (int k = 0; k < K; k++) {
         if (C::NSLOT == 2 && k + 1 < K) {
             issue_frame(k + 1);                                         // its slot was last read in frame k-1: the barrier below is behind us
             wait_vmcnt<C::NPT>();                                       // frame k has landed, frame k+1 may still be on its way
         } else wait_vmcnt<0>();
-        lds_barrier();                                                  // frame k is in for everyone
+        lds_barrier();                                                  // frame k is in for everyone (and frame k-1 has been read for the last time)
+        if (C::MUBUFS == 1 && (k & 1) == 0) issue_means(k);             // one buffer for the means: free now, needed at the first row filter
         const pair_t* img = reinterpret_cast<const pair_t*>(ring + (k % C::NSLOT) * C::SLOT);
         const pair_t* la = img + pr * C::PA + pqb * (QB / 2);
         const pair_t* lb = img + C::OFF_B + pr * C::PB + pqb * (QB / 2);
@@ -305,7 +316,7 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
             continue;
         }
         // ---- DF: one filter round per column offset on this frame's w, w a, w b
-        const pair_t* mup = reinterpret_cast<const pair_t*>(mubuf + ((k >> 1) & 1) * C::MU_DMA);
+        const pair_t* mup = reinterpret_cast<const pair_t*>(mubuf + (C::MUBUFS == 2 ? ((k >> 1) & 1) : 0) * C::MU_DMA);
 #pragma unroll
         for (int u = 0; u < UB; u++) {
             if (u < nu) {                                               // (uniform)
@@ -313,7 +324,7 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
                 if (pactive) products(u, w_, wa_, wb_);
                 if (u == nu - 1) {                                      // last read of the slot: frame k+1 flies during this round
                     lds_barrier();
-                    if (k + 1 < K) issue_frame(k + 1);
+                    if (k + 1 < K) { issue_frame(k + 1); if (C::MUBUFS == 2 && ((k + 1) & 1) == 0) issue_means(k + 1); }
                 } else if (u > 0) __syncthreads();                      // the previous round's row filter has read the planes
                 if (pactive) {
 #pragma unroll
@@ -327,6 +338,10 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
                     }
                 }
                 filter_cols();
+                if (C::MUBUFS == 1 && u == 0 && (k & 1) == 0) {             // the means issued at the head of this frame have landed for everyone
+                    wait_vmcnt<0>();
+                    __syncthreads();
+                }
                 // the means of this item's pixels at the reference window (Model.cpp:808)
                 double mu[C::CB];
                 if (A.ablate & 1) {
@@ -416,21 +431,21 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
 }
 
 // one workgroup = one (tile, pass) of a static grid (od_static_item, umpa_corr.h)
-template <int KIND, int NW, int UB>
-__global__ void __launch_bounds__(512, 2)
+template <int KIND, int NW, int UB, int TCT>
+__global__ void __launch_bounds__((MaskCfg<KIND, NW, UB, TCT>::NT), 2)
 corr_masked_kernel(ModelDev m, MaskedArgs A, Sep1D sep, OdCorr od)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int UJ = 2 * m.ms - 1, npass = UJ * ((UJ + UB - 1) / UB);
     int lin, pass;
     if (!od_static_item(od, A.ntx, A.ntx * A.nty, npass, lin, pass)) return;
-    corr_masked_tile<KIND, NW, UB>(m, A, sep, reinterpret_cast<double*>(smem_raw), lin, pass, threadIdx.x);
+    corr_masked_tile<KIND, NW, UB, TCT>(m, A, sep, reinterpret_cast<double*>(smem_raw), lin, pass, threadIdx.x);
     od_mark_done(od, lin, pass);
 }
 
 // the same over a work list, by a persistent grid (the repair step of umpa_ondemand.h)
-template <int KIND, int NW, int UB>
-__global__ void __launch_bounds__(512, 2)
+template <int KIND, int NW, int UB, int TCT>
+__global__ void __launch_bounds__((MaskCfg<KIND, NW, UB, TCT>::NT), 2)
 corr_masked_queue_kernel(ModelDev m, MaskedArgs A, Sep1D sep, OdCorr od)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -442,7 +457,7 @@ corr_masked_queue_kernel(ModelDev m, MaskedArgs A, Sep1D sep, OdCorr od)
         if (idx < 0) break;
         const int it = __builtin_amdgcn_readfirstlane(gp(od.items)[idx]);
         if (j) __syncthreads();                                         // the previous item's last LDS reads
-        corr_masked_tile<KIND, NW, UB>(m, A, sep, reinterpret_cast<double*>(smem_raw), it >> 8, it & 255, tid);
+        corr_masked_tile<KIND, NW, UB, TCT>(m, A, sep, reinterpret_cast<double*>(smem_raw), it >> 8, it & 255, tid);
         od_mark_done(od, it >> 8, it & 255);
     }
 }

@@ -951,6 +951,13 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
 template <int KIND, int NW>
 constexpr int masked_ub() { return KIND == 1 ? (NW <= 6 ? 3 : 2) : (NW <= 6 ? 5 : 3); }
 
+// Tile width of the masked table kernel.  MaskCfg also describes 32 x 16 tiles with two 256-thread workgroups per CU
+// (TC_ = 16: a single buffer for the means, 6 columns per product thread); measured on C2 + mask, dark-field: 24.1 against
+// 21.5 ms for one 512-thread workgroup on 32 x 32 tiles -- 21 % more halo in the products, a quarter more staging per pixel
+// and 32 spilled registers outweigh what two independent workgroups overlap.  Not instantiated.
+template <int KIND, int NW>
+constexpr int masked_tc_narrow() { return 32; }
+
 template <int NW>
 constexpr bool masked_cfg_ok() { return MaskCfg<0, NW, masked_ub<0, NW>()>::OK && MaskCfg<1, NW, masked_ub<1, NW>()>::OK; }
 
@@ -961,11 +968,11 @@ inline bool masked_supported(int Nw)
     return ok;
 }
 
-template <int KIND, int NW>
-inline hipError_t launch_masked(const ModelDev& dev, MaskedArgs A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
+template <int KIND, int NW, int TCT>
+inline hipError_t launch_masked_tc(const ModelDev& dev, MaskedArgs A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     constexpr int UBM = masked_ub<KIND, NW>();
-    using C = MaskCfg<KIND, NW, UBM>;
+    using C = MaskCfg<KIND, NW, UBM, TCT>;
     if constexpr (!C::OK) return hipErrorInvalidValue;
     else {
         A.ntx = (A.N1 + C::TC - 1) / C::TC;
@@ -987,33 +994,33 @@ inline hipError_t launch_masked(const ModelDev& dev, MaskedArgs A, const Sep1D& 
         {
             std::lock_guard<std::mutex> lock(tiled_attr_mutex());
             if (!attr_set[devid & 63]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_masked_kernel<KIND, NW, UBM>),
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_masked_kernel<KIND, NW, UBM, TCT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_masked_queue_kernel<KIND, NW, UBM, TCT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
                 if (e != hipSuccess) return e;
                 attr_set[devid & 63] = true;
             }
         }
         const OdCorr oc = od_corr_args(L.od);
         if (L.od.mode == 2) {
-            static bool qattr_set[64] = {};
-            {
-                std::lock_guard<std::mutex> lock(tiled_attr_mutex());
-                if (!qattr_set[devid & 63]) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_masked_queue_kernel<KIND, NW, UBM>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
-                    if (e != hipSuccess) return e;
-                    qattr_set[devid & 63] = true;
-                }
-            }
-            const int grid = ((device_cu_count() + 7) / 8) * 8;             // one 512-thread workgroup per CU
-            hipLaunchKernelGGL((corr_masked_queue_kernel<KIND, NW, UBM>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
+            const int grid = ((device_cu_count() * C::WPC + 7) / 8) * 8;       // persistent: one workgroup per slot of the chip
+            hipLaunchKernelGGL((corr_masked_queue_kernel<KIND, NW, UBM, TCT>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
         } else {
             const int nt = L.od.mode == 3 ? oc.nseed : A.ntx * A.nty;
             const int grid = 8 * ((nt + 7) / 8) * npass;
-            if (nt > 0) hipLaunchKernelGGL((corr_masked_kernel<KIND, NW, UBM>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
+            if (nt > 0) hipLaunchKernelGGL((corr_masked_kernel<KIND, NW, UBM, TCT>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
         }
         return hipGetLastError();
     }
+}
+
+template <int KIND, int NW>
+inline hipError_t launch_masked(const ModelDev& dev, const MaskedArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
+{
+    constexpr int TCN = masked_tc_narrow<KIND, NW>();
+    return launch_masked_tc<KIND, NW, TCN>(dev, A, sep, s, L);
 }
 
 // One match of a region of a masked model.  Returns 0, -3 (allocation) or a positive hipError_t.
