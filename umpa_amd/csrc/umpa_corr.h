@@ -62,7 +62,7 @@ struct CorrArgs {
     int sigma;                // +1: B = ref sits at p+u ('sam' mode); -1: B = sam sits at p-u ('ref' mode)
     int ntx, nty;
     int br0, br1, bc0, bc1, Wf;   // rows / columns of the image inside every frame, the frames' common width (Maps, umpa_tiled.h)
-    int ablate;               // diagnostics only (UMPA_HIP_ABLATE): 1 no global loads, 4 no products, 8 no filters
+    int ablate;               // diagnostics only (UMPA_HIP_ABLATE): 1 no global loads, 4 no products, 8 no filters, 16 no table stores
 };
 
 #define UMPA_LDS_AS __attribute__((address_space(3)))
@@ -380,7 +380,7 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
                             const double give = odd ? out[2 * h] : out[2 * h + 1];
                             const double got = swap_adjacent_lanes(give);           // the neighbour column's value of MY row
                             const int o = 2 * h + odd, row = prow0 + rb * C::CB + o;
-                            if (row < A.row0 + A.rows && col < A.N1) {
+                            if (row < A.row0 + A.rows && col < A.N1 && !(A.ablate & 16)) {     // (ablation 16: everything but the table stores)
                                 pair_t v2; v2[0] = odd ? got : mine; v2[1] = odd ? mine : got;
                                 store_table16(dst + (size_t)o * A.N1 - odd, v2);
                             }

@@ -599,6 +599,8 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // 42-44; 384 threads 46.1-51.6.
 // Per workgroup and pass (s_memtime, 32x32 / 256 / 2 per CU, issue at the head): frame loop 37 k cycles, flush 21 k
 // (planes to LDS 3.5 k, column filter 5.2 k, write back 2.5 k, row filter + stores 9.6 k).
+// (round 3: 32x32 / 512 threads (4 columns per product thread) / TWO per CU, two or three flush rounds: 1.72-1.73 against 1.70 for
+// shape 1 on the same box -- twice the waves change nothing: the kernel is not short of waves)
 #define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 2) X(2, 24, 256, 1, 2, 2) X(3, 16, 256, 1, 2, 1) X(4, 32, 512, 1, 1, 2)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
