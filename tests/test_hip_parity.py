@@ -352,7 +352,8 @@ def test_stepped_and_chunked_tiled_path_matches_direct(hip_ns, monkeypatch):
         m.debug = "ncalls"
         m._force = _lib.F_FORCE_TILED if force == "tiled" else _lib.F_FORCE_DIRECT
         res[force] = [m.match(ROI=((3, 380, 2), (5, 280, 3)), quiet=True), m.match(step=3, quiet=True),
-                      m.match(ROI=((0, 386, 1), (0, 286, 1)), quiet=True)]
+                      m.match(ROI=((0, 386, 1), (0, 286, 1)), quiet=True), m.match(step=5, quiet=True),
+                      m.match(ROI=((2, 385, 7), (1, 285, 4)), quiet=True)]
         assert m._lib.last_path(m._handle) in ((2,) if force == "tiled" else (1, 3))
     for a, b in zip(res["tiled"], res["direct"]):
         np.testing.assert_array_equal(a["err"], b["err"])
@@ -364,7 +365,7 @@ def test_stepped_and_chunked_tiled_path_matches_direct(hip_ns, monkeypatch):
     with pytest.raises(_lib.NativeError, match="does not cover"):
         m = hip_ns.UMPAModelDF(sam, ref, window_size=3, max_shift=4)
         m._force = _lib.F_FORCE_TILED
-        m.match(step=4, quiet=True)                       # 16 dense pixels per output pixel: left to the direct kernel
+        m.match(step=10, quiet=True)                      # 100 dense pixels per output pixel: left to the direct kernel
 
 
 def test_degenerate_sizes_on_device(hip_ns, port_ns):

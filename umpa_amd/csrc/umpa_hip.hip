@@ -366,7 +366,7 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
 
 // Can the tiled fast path take this model and region?  (see umpa_tiled.h for what it covers; frame positions are
 // dealt with by run_match)
-bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
+bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A, bool forced = false)
 {
     if (m->kind == UMPA_HIP_KIND_DFKERNEL) return false;
     if (m->has_mask && !masked_supported(m->Nw)) return false;        // corr_masked + replay_cost (umpa_masked.h)
@@ -374,9 +374,21 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A)
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
     // corr_volume / corr_masked address a frame with 32-bit byte offsets (LDS-DMA source = base + per-lane offset)
     if ((size_t)m->dims[0] * m->dims[1] * sizeof(double) >= ((size_t)1 << 32)) return false;
-    // stepped regions: the tiled kernels still compute the dense grid, which pays while step0*step1 is small
-    // (the direct kernel's cost is per requested pixel, about 20x the tiled cost per dense pixel)
-    if (A.step0 * A.step1 > 9) return false;
+    // stepped regions: the tiled kernels still compute the dense grid, the direct kernel only the requested pixels at
+    // about 20 costs each.  Measured on 2048^2 x 10 frames, Nw 5, max_shift 5 (tools/step_rate.py): step 3: 3.5 vs 9.8 ms,
+    // 4: 2.5 vs 7.6, 5: 2.4 vs 6.8, 6: 2.4 vs 5.0 -- the dense grid wins up to about 64 dense pixels per requested
+    // one there.  The table grows with the number of shifts, the direct walk does not: the limit scales with 81 / planes.
+    // Masked models cost 7x (NoDF 2x) more per dense pixel on the tiled path and about the same on the direct one.
+    {
+        static const char* se = getenv("UMPA_HIP_TILED_MAX_STEP2");   // tuning override
+        const int planes = (2 * m->ms - 1) * (2 * m->ms - 1);
+        const int base = !m->has_mask ? 64 : m->kind == UMPA_HIP_KIND_NODF ? 16 : 5;
+        int lim = planes <= 81 ? base : base * 81 / planes;
+        if (lim < 1) lim = 1;
+        if (se) lim = atoi(se);
+        if (forced && lim < 81) lim = 81;                              // UMPA_HIP_F_FORCE_TILED: the caller's choice, not the economics
+        if (A.step0 * A.step1 > lim) return false;
+    }
     // the exhaustive table has (2 max_shift - 1)^2 planes: beyond a few hundred shifts the lazy evaluation of the
     // direct kernel (about 20 costs per pixel) is less work than filling it
     if ((2 * m->ms - 1) * (2 * m->ms - 1) > 1089) return false;
@@ -491,7 +503,7 @@ int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0,
 int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
               int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
 {
-    const bool can_tile = tiled_applicable(m, A);
+    const bool can_tile = tiled_applicable(m, A, (flags & UMPA_HIP_F_FORCE_TILED) != 0);
     const StepGeom g = can_tile ? step_geometry(m, A) : StepGeom();
     const bool whole = can_tile && (!g.any_pos || (g.a0 == 0 && g.b0 == A.N0 && g.a1 == 0 && g.b1 == A.N1));
     // sample stepping: the tiled path takes the rectangle every frame contributes to, the general kernels the border
