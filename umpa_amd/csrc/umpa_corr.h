@@ -53,6 +53,22 @@ __device__ __forceinline__ void fir_block(const double* __restrict__ in, int str
     }
 }
 
+// The same sums in the same order, one input at a time: 8 running outputs instead of CB + 2NW inputs in registers.
+template <int NW, int CB>
+__device__ __forceinline__ void fir_running(const double* __restrict__ in, int stride, const double* h, double* out)
+{
+    constexpr int S = 2 * NW + 1;
+#pragma unroll
+    for (int o = 0; o < CB; o++) out[o] = 0.0;
+#pragma unroll
+    for (int t = 0; t < CB + S - 1; t++) {
+        const double v = in[t * stride];
+#pragma unroll
+        for (int o = 0; o < CB; o++)
+            if (t - o >= 0 && t - o < S) out[o] = fma(h[t - o], v, out[o]);
+    }
+}
+
 struct CorrArgs {
     double* table;            // [(2ms-1)^2][rows][N1]
     size_t slot_stride;       // rows * N1
@@ -76,16 +92,21 @@ struct CorrArgs {
 // offset oi0 + g, all groups share the staged frames (the A image, and a B image of QR + UI - 1 rows), so a pass
 // produces UI * UB planes from one staging.  WPC workgroups share a CU, so one may use LDSB = 160 KiB / WPC of
 // LDS; the planes are filtered and stored in NF rounds of PR planes (fewer planes in LDS at a time).
-template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+// RO > 1: every product thread accumulates RO consecutive row offsets (all reading ONE staged B image of QR + RO - 1 rows):
+// a pass produces RO * UB planes from one staging, a third of the L2 -> LDS traffic per plane at RO = 3.  The accumulators
+// then fill the register file (4 x 9 x 3 doubles per thread on 32x32 tiles), so the flush goes in rounds of few planes with
+// the column filter writing to a second LDS area (nothing is held in registers across a barrier).
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF, int RO = 1>
 struct CorrCfg {
     static constexpr int NT = NTG * UI;
+    static constexpr int NROW = UI * RO;                  // row offsets per pass
     static constexpr int TR = UMPA_TILE, S = 2 * NW + 1;
     static constexpr int LDSB = (UMPA_LDS_BUDGET / WPC) & ~15;
-    static constexpr int NPL = UI * UB;                   // planes per pass
+    static constexpr int NPL = NROW * UB;                 // planes per pass
     static constexpr int PR = (NPL + NF - 1) / NF;        // planes per flush round
     static constexpr int WPS = (NT / 64 * WPC + 3) / 4;   // waves per SIMD this shape is built for
     static constexpr int QR = TR + 2 * NW, QC = TC + 2 * NW;  // q-region (tile + window halo): rows, columns
-    static constexpr int QRB = QR + UI - 1;               // rows of the B image
+    static constexpr int QRB = QR + NROW - 1;             // rows of the B image
     static constexpr int QP = QR | 1;                     // odd pitch of the transposed product planes ([column][row])
     // one product plane; padded so that PPL = QR (mod 32): the column filter's lanes run over the rows of one
     // (plane, column block) after the other, plane fastest, and with this pitch the LDS bank sequence continues
@@ -97,21 +118,34 @@ struct CorrCfg {
     static constexpr int NBP = (QB + UB) / 2;             // B column pairs a thread reads: ceil((QB+UB-1)/2)
     static constexpr int BW = (QC + UB) & ~1;             // B columns staged, even
     static constexpr int PA = (QC / 2) | 1, PB = (BW / 2) | 1;   // 16-byte pieces per image row: odd
-    static constexpr int NPIECE = QR * PA + QRB * PB;     // pieces of one staged frame: A image then B image
+    // pieces of one staged frame: A image, then B image from a multiple of 64 pieces on -- a wave-instruction (64 pieces)
+    // then reads one stack only, and its base address is a scalar (SGPR base + 32-bit lane offset)
+    static constexpr int APIECES = (QR * PA + 63) & ~63;
+    static constexpr int NPIECE = APIECES + QRB * PB;
     static constexpr int NPT = (NPIECE + NT - 1) / NT;    // LDS-DMA instructions per thread and frame
     static constexpr int SLOT = NPT * NT * 2;             // doubles per frame slot (every lane of every instruction writes)
     // the last block's threads read past the end of their image row, on the last row past the image:
-    static constexpr int OVER = 2 * (NQB * (QB / 2) - (QB / 2) + NBP) - 2 * PB;
+    // (every thread multiplies, also those past the last column block -- no divergence in the frame loop; what they
+    // read is never stored)
+    static constexpr int NQBX = (NTG + QR - 1) / QR;
+    static constexpr int OVER = 2 * (NQBX * (QB / 2) - (QB / 2) + NBP) - 2 * PB;
     static constexpr int TAIL = NPIECE * 2 + (OVER > 0 ? OVER : 0);             // doubles of the last slot that are touched
     static constexpr int NSLOT_FIT = (LDSB / 8 - (TAIL > SLOT ? TAIL - SLOT : 0)) / SLOT;
     static constexpr int NSLOT = NSLOT_FIT > 4 ? 4 : NSLOT_FIT;               // ring depth: NSLOT-1 frames in flight
     static constexpr int RING = NSLOT * SLOT + (TAIL > SLOT ? TAIL - SLOT : 0);
-    static constexpr int LDS_DOUBLES = RING > PR * PPL ? RING : PR * PPL;
+    // RO > 1: the column-filtered planes live beside the raw ones, [column][row] with the even row pitch HQP = 2 (mod 4): the
+    // row filter's lanes (one column each) read 16-byte aligned row pairs (ds_read_b128), 16 lanes of a group in 16
+    // different 16-byte slots of the 256-byte bank row
+    static constexpr int HQP = QR + ((6 - QR % 4) % 4);
+    static constexpr int HPL = TC * HQP;
+    static constexpr int FLUSH = PR * PPL + (RO > 1 ? PR * HPL : 0);
+    static constexpr int LDS_DOUBLES = RING > FLUSH ? RING : FLUSH;
     static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
     static constexpr int CB = 8;                          // outputs per filter item
     static constexpr int HITEMS = PR * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
-    static constexpr bool OK = NSLOT >= 2 && PR * PPL * 8 <= LDSB && QR * NQB <= NTG && (NSLOT - 1) * NPT < 64 &&
-                               LDS_DOUBLES * 8 <= LDSB && NTG % 64 == 0 && NT <= 1024 && WPS <= 8;
+    static constexpr bool OK = NSLOT >= 2 && FLUSH * 8 <= LDSB && QR * NQB <= NTG && (NSLOT - 1) * NPT < 64 &&
+                               LDS_DOUBLES * 8 <= LDSB && NTG % 64 == 0 && NT <= 1024 && WPS <= 8 && (RO == 1 || UI == 1) &&
+                               QB * UB * RO <= 112;
 };
 
 // 16-byte store of two table entries, non-temporal (`nt`): the 2.7 GB streaming out no longer push the frame patches
@@ -146,12 +180,20 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
+// One LDS-DMA wave-instruction: lane l copies the 16 bytes at base + off (its own offset) to dst + 16 l.  `base` is
+// wave-uniform: buffer addressing (SGPR descriptor + 32-bit lane offset) needs no 64-bit address per lane.
+__device__ __forceinline__ void lds_dma16(const UMPA_GLOBAL char* base, unsigned off, UMPA_LDS_AS char* dst)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, -1, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (UMPA_LDS_AS void*)dst, 16, (int)off, 0, 0, 0);
+}
+
 // the planes of one (tile, pass) into the table
-template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF, int RO>
 __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrArgs& A, const Sep1D& sep, double* lds,
                                                  const int lin, const int pass, const int tid)
 {
-    using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>;
+    using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF, RO>;
     constexpr int NT = C::NT;
     const int ms = m.ms, UJ = 2 * ms - 1;
     const int nbatch = (UJ + UB - 1) / UB;
@@ -160,28 +202,29 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
     const int grp = UI > 1 ? __builtin_amdgcn_readfirstlane(tid / NTG) : 0, gtid = tid - grp * NTG;
     const int prow0 = A.row0 + ty * C::TR, pcol0 = tx * TC;           // first output pixel of the tile (region coords)
     const int fr0 = A.org0 + prow0 - NW, fc0 = A.org1 + pcol0 - NW;   // frame coords of the q-region origin
-    const int oi0 = (pass / nbatch) * UI - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
+    const int oi0 = (pass / nbatch) * C::NROW - (ms - 1), oj0 = (pass % nbatch) * UB - (ms - 1);
 
     // ---- LDS-DMA slots of this thread: piece p = tid + n*NT of the frame image (A rows, then B rows); its source
     // is 16 bytes = two adjacent columns of one frame row.  Pieces past the image (padding of the last instruction,
     // the pad piece of an image row) read a clamped address and land in bytes nobody uses.
     unsigned src_off[C::NPT];                                         // byte offset inside a frame
-    unsigned src_isB = 0;                                             // bit n: piece n comes from the B stack
 #pragma unroll
     for (int n = 0; n < C::NPT; n++) {
         const int p = tid + n * NT;
         int r, c;
-        bool isB = p >= C::QR * C::PA;
-        if (!isB) { r = p / C::PA; c = 2 * (p % C::PA); }
+        if (p < C::APIECES) { r = p / C::PA; c = 2 * (p % C::PA); }
         else {
-            const int q = min(p - C::QR * C::PA, C::QRB * C::PB - 1);
+            const int q = min(p - C::APIECES, C::QRB * C::PB - 1);
             r = q / C::PB + oi0; c = 2 * (q % C::PB) + oj0;
         }
         const int gr = min(max(fr0 + r, A.br0), A.br1), gc = min(max(fc0 + c, A.bc0), A.bc1 - 1);
         src_off[n] = (unsigned)(gr * A.Wf + gc) * 8u;
-        if (isB) src_isB |= 1u << n;
     }
     const unsigned wave_piece0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);   // first piece of this wave's instruction 0
+    unsigned src_isB = 0;                                             // bit n: instruction n of this wave reads the B stack (wave-uniform)
+#pragma unroll
+    for (int n = 0; n < C::NPT; n++)
+        if (wave_piece0 + n * NT >= (unsigned)C::APIECES) src_isB |= 1u << n;
 
     auto issue_frame = [&](int k) {                                   // frame k -> ring slot k % NSLOT
         const FrameDesc fd = load_frame(m.frames, k);
@@ -190,23 +233,23 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
         const UMPA_GLOBAL char* gB = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fd.ref : fd.sam) - shift;
         UMPA_LDS_AS char* slot = (UMPA_LDS_AS char*)(lds + (k % C::NSLOT) * C::SLOT);
 #pragma unroll
-        for (int n = 0; n < C::NPT; n++) {
-            const UMPA_GLOBAL char* src = ((src_isB >> n) & 1u ? gB : gA) + src_off[n];
-            __builtin_amdgcn_global_load_lds(src, slot + (size_t)(wave_piece0 + n * NT) * 16, 16, 0, 0);
-        }
+        for (int n = 0; n < C::NPT; n++)
+            lds_dma16((src_isB >> n) & 1u ? gB : gA, src_off[n], slot + (size_t)(wave_piece0 + n * NT) * 16);
     };
 
     // product-stage ownership inside the group: (qb, r), r fastest; a group whose row offset is past the search
     // range (the last pass when UI does not divide 2 ms - 1) only helps with the staging and the filters
     const int pr = gtid % C::QR, pqb = gtid / C::QR;
-    const bool gvalid = oi0 + grp <= ms - 1;
-    const bool pactive = pqb < C::NQB && gvalid;
+    const bool gvalid = oi0 + grp * RO <= ms - 1;
+    const bool pactive = pqb < C::NQB && gvalid;                       // owns accumulators that reach the table
     typedef double pair_t __attribute__((ext_vector_type(2)));
-    double acc[C::QB][UB];
+    double acc[RO][C::QB][UB];
 #pragma unroll
-    for (int t = 0; t < C::QB; t++)
+    for (int ro = 0; ro < RO; ro++)
 #pragma unroll
-        for (int u = 0; u < UB; u++) acc[t][u] = 0.0;
+        for (int t = 0; t < C::QB; t++)
+#pragma unroll
+            for (int u = 0; u < UB; u++) acc[ro][t][u] = 0.0;
 
     const int K = m.Na;
     constexpr int D = C::NSLOT - 1;                                   // frames in flight behind the one in use
@@ -218,7 +261,7 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
     // One frame step.  ISSUE: frame k+D exists and its DMA instructions go out BETWEEN the product rows of frame k, one
     // per QB-th of the FMAs (straight-line code, pinned with sched_barrier): a wave that issues them all at once sits in
     // the issue queue of the memory pipeline instead of multiplying.
-    const bool dma = !(A.ablate & 1), prod = pactive && !(A.ablate & 4);
+    const bool dma = !(A.ablate & 1), prod = gvalid && !(A.ablate & 4);     // (wave-uniform)
     auto frame_step = [&](int k, auto ISSUE, auto DRAIN) {
         // frames k .. k+D-1 have been issued, in order: frame k has landed when at most (D-1)*NPT are outstanding
         if constexpr (decltype(DRAIN)::value) wait_vmcnt<0>(); else wait_vmcnt<(D - 1) * C::NPT>();
@@ -230,30 +273,59 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
         const UMPA_GLOBAL char* gBn = (const UMPA_GLOBAL char*)gp(A.sigma > 0 ? fdn.ref : fdn.sam) - shiftn;
         UMPA_LDS_AS char* slotn = (UMPA_LDS_AS char*)(lds + ((k + D) % C::NSLOT) * C::SLOT);
         auto issue_piece = [&](int n) {
-            const UMPA_GLOBAL char* src = ((src_isB >> n) & 1u ? gBn : gAn) + src_off[n];
-            __builtin_amdgcn_global_load_lds(src, slotn + (size_t)(wave_piece0 + n * NT) * 16, 16, 0, 0);
+            lds_dma16((src_isB >> n) & 1u ? gBn : gAn, src_off[n], slotn + (size_t)(wave_piece0 + n * NT) * 16);
         };
         constexpr int PER = (C::NPT + C::QB - 1) / C::QB;            // DMA instructions per product row
         if (prod) {
             const pair_t* img = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT);
             const pair_t* la = img + pr * C::PA + pqb * (C::QB / 2);
-            const pair_t* lb = img + C::QR * C::PA + (pr + grp) * C::PB + pqb * (C::QB / 2);
-            pair_t av[C::QB / 2], bv[C::NBP];
+            const pair_t* lb = img + C::APIECES + (pr + grp * RO) * C::PB + pqb * (C::QB / 2);
+            pair_t av[C::QB / 2], bv0[C::NBP];
 #pragma unroll
             for (int t = 0; t < C::QB / 2; t++) av[t] = la[t];
+            if constexpr (RO > 1) {
+                // the accumulators fill the register file: the B row comes in two halves, each with the FMAs that need
+                // nothing else (column sums t + u below / from HB), so that only half a row has to be in registers
+                constexpr int HP = C::NBP / 2, HB = 2 * HP;           // pairs / B columns of the first half
 #pragma unroll
-            for (int t = 0; t < C::NBP; t++) bv[t] = lb[t];
+                for (int ro = 0; ro < RO; ro++) {
 #pragma unroll
-            for (int t = 0; t < C::QB; t++) {
-                if constexpr (issue) {
+                    for (int half = 0; half < 2; half++) {
+                        constexpr int SL = 2 * RO;                    // slots the DMA instructions are spread over
+                        if constexpr (issue) {
 #pragma unroll
-                    for (int q = 0; q < PER; q++)
-                        if (t * PER + q < C::NPT) issue_piece(t * PER + q);
-                    __builtin_amdgcn_sched_barrier(0);
+                            for (int n = 0; n < C::NPT; n++)
+                                if (n % SL == ro * 2 + half) issue_piece(n);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        pair_t bv[C::NBP];
+#pragma unroll
+                        for (int t = 0; t < C::NBP; t++)
+                            if ((t < HP) == (half == 0)) bv[t] = lb[ro * C::PB + t];
+#pragma unroll
+                        for (int t = 0; t < C::QB; t++)
+#pragma unroll
+                            for (int u = 0; u < UB; u++)
+                                if ((t + u < HB) == (half == 0))
+                                    acc[ro][t][u] = fma(av[t >> 1][t & 1], bv[(t + u) >> 1][(t + u) & 1], acc[ro][t][u]);
+                        if constexpr (issue) __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+            } else {
 #pragma unroll
-                for (int u = 0; u < UB; u++) acc[t][u] = fma(av[t >> 1][t & 1], bv[(t + u) >> 1][(t + u) & 1], acc[t][u]);
-                if constexpr (issue) __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < C::NBP; t++) bv0[t] = lb[t];
+#pragma unroll
+                for (int t = 0; t < C::QB; t++) {
+                    if constexpr (issue) {
+#pragma unroll
+                        for (int q = 0; q < PER; q++)
+                            if (t * PER + q < C::NPT) issue_piece(t * PER + q);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; u++) acc[0][t][u] = fma(av[t >> 1][t & 1], bv0[(t + u) >> 1][(t + u) & 1], acc[0][t][u]);
+                    if constexpr (issue) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else if constexpr (issue) {
 #pragma unroll
@@ -273,16 +345,20 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
             if (!prod) return;
             const pair_t* img = reinterpret_cast<const pair_t*>(lds + (k % C::NSLOT) * C::SLOT);
             const pair_t* la = img + pr * C::PA + pqb * (C::QB / 2);
-            const pair_t* lb = img + C::QR * C::PA + (pr + grp) * C::PB + pqb * (C::QB / 2);
-            pair_t av[C::QB / 2], bv[C::NBP];
+            const pair_t* lb = img + C::APIECES + (pr + grp * RO) * C::PB + pqb * (C::QB / 2);
+            pair_t av[C::QB / 2];
 #pragma unroll
             for (int t = 0; t < C::QB / 2; t++) av[t] = la[t];
 #pragma unroll
-            for (int t = 0; t < C::NBP; t++) bv[t] = lb[t];
+            for (int ro = 0; ro < RO; ro++) {
+                pair_t bv[C::NBP];
 #pragma unroll
-            for (int t = 0; t < C::QB; t++)
+                for (int t = 0; t < C::NBP; t++) bv[t] = lb[ro * C::PB + t];
 #pragma unroll
-                for (int u = 0; u < UB; u++) acc[t][u] = fma(av[t >> 1][t & 1], bv[(t + u) >> 1][(t + u) & 1], acc[t][u]);
+                for (int t = 0; t < C::QB; t++)
+#pragma unroll
+                    for (int u = 0; u < UB; u++) acc[ro][t][u] = fma(av[t >> 1][t & 1], bv[(t + u) >> 1][(t + u) & 1], acc[ro][t][u]);
+            }
         };
         for (int k = 0; k < K; k++) {
             // frames k+1 .. min(k+NSLOT-1, K-1) may still be on their way
@@ -316,42 +392,97 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
     const bool vec_ok = (A.N1 & 1) == 0;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-        __syncthreads();                                              // frames (or the previous round's planes) consumed
+        // frames (or the previous round's planes) consumed.  RO > 1: the raw planes were last read before the barrier in
+        // front of the previous round's row filter, so only the first round has to wait here
+        if (RO == 1 || f == 0) __syncthreads();
         if (pactive) {
-            const int l0 = grp * UB - f * PR;                         // round-local index of this group's plane u = 0
 #pragma unroll
-            for (int t = 0; t < C::QB; t++) {
-                const int c = pqb * C::QB + t;
-                if (c < C::QC) {
+            for (int ro = 0; ro < RO; ro++) {
+                const int l0 = (grp * RO + ro) * UB - f * PR;         // round-local index of this row offset's plane u = 0
 #pragma unroll
-                    for (int u = 0; u < UB; u++)
-                        if (l0 + u >= 0 && l0 + u < PR) lds[(l0 + u) * C::PPL + c * C::QP + pr] = acc[t][u];
+                for (int t = 0; t < C::QB; t++) {
+                    const int c = pqb * C::QB + t;
+                    if (c < C::QC) {
+#pragma unroll
+                        for (int u = 0; u < UB; u++)
+                            if (l0 + u >= 0 && l0 + u < PR) lds[(l0 + u) * C::PPL + c * C::QP + pr] = acc[ro][t][u];
+                    }
                 }
             }
         }
         __syncthreads();
-        // H stage (along columns), results kept in registers, then written in place
-        double hres[C::HROUNDS][C::CB];
+        const double* vsrc = lds;                                     // what the row filter reads
+        int vpitch = C::PPL;
+        if constexpr (RO > 1) {
+            // H stage (along columns) into the second area
+            double* hout = lds + PR * C::PPL;
 #pragma unroll
-        for (int rd = 0; rd < C::HROUNDS; rd++) {
-            const int it = tid + rd * NT;
-            if (it < C::HITEMS) {
-                const int r = it % C::QR, rest = it / C::QR, u = rest % PR, cb = rest / PR;
-                fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
+            for (int rd = 0; rd < C::HROUNDS; rd++) {
+                const int it = tid + rd * NT;
+                if (it < C::HITEMS) {
+                    const int r = it % C::QR, rest = it / C::QR, u = rest % PR, cb = rest / PR;
+                    double hres[C::CB];
+                    fir_running<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres);
+                    double* dst = hout + u * C::HPL + (cb * C::CB) * C::HQP + r;
+#pragma unroll
+                    for (int o = 0; o < C::CB; o++) dst[o * C::HQP] = hres[o];
+                }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            // V stage (along rows) and store, one item per thread and round: (plane of the round, row block, column) with the
+            // plane wave-uniform -- the table slot's base address is a scalar, the lane's offset inside a slot is the same in
+            // every round.  Column pairs swap half of their rows as below.  Tiles that reach over the region's edge, and odd
+            // N1, take the general code.
+            static_assert(PR * (C::TR / C::CB) * TC <= NT && (TC * (C::TR / C::CB)) % 64 == 0 && TC == 32, "one item per thread, plane per wave");
+            const bool inside = prow0 + C::TR <= A.row0 + A.rows && pcol0 + TC <= A.N1 && vec_ok && !(A.ablate & 16);
+            if (inside) {
+                const int pl = __builtin_amdgcn_readfirstlane(tid / (TC * (C::TR / C::CB)));
+                const int P = f * PR + pl, g = P / UB, u = P - g * UB;
+                if (pl < PR && P < C::NPL && u < nu && oi0 + g <= ms - 1) {
+                    const int c = tid % TC, rb = (tid / TC) % (C::TR / C::CB), odd = c & 1;
+                    double out[C::CB];
+                    fir_running<NW, C::CB>(reinterpret_cast<const double*>(__builtin_assume_aligned(hout + pl * C::HPL + c * C::HQP + rb * C::CB, 16)),
+                                           1, sep.hr, out);
+                    const int ui = A.sigma * (oi0 + g), uj = A.sigma * (oj0 + u);
+                    const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
+                    UMPA_GLOBAL double* sbase = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 - A.row0) * A.N1 + pcol0;   // scalar
+                    const unsigned voff = (unsigned)((rb * C::CB + odd) * A.N1 + c - odd) * 8u;     // this lane's bytes from there
 #pragma unroll
-        for (int rd = 0; rd < C::HROUNDS; rd++) {
-            const int it = tid + rd * NT;
-            if (it < C::HITEMS) {
-                const int r = it % C::QR, rest = it / C::QR, u = rest % PR, cb = rest / PR;
-                double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
-#pragma unroll
-                for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
+                    for (int h = 0; h < C::CB / 2; h++) {
+                        const double give = odd ? out[2 * h] : out[2 * h + 1];
+                        const double got = swap_adjacent_lanes(give);
+                        pair_t v2; v2[0] = odd ? got : out[2 * h]; v2[1] = odd ? out[2 * h + 1] : got;
+                        UMPA_GLOBAL char* rowp = reinterpret_cast<UMPA_GLOBAL char*>(sbase + (size_t)(2 * h) * A.N1);
+                        __builtin_nontemporal_store(v2, reinterpret_cast<UMPA_GLOBAL table_pair_t*>(rowp + voff));
+                    }
+                }
+                continue;                                             // next round
             }
+            vsrc = hout; vpitch = C::HPL;
+        } else {
+            // H stage (along columns), results kept in registers, then written in place
+            double hres[C::HROUNDS][C::CB];
+#pragma unroll
+            for (int rd = 0; rd < C::HROUNDS; rd++) {
+                const int it = tid + rd * NT;
+                if (it < C::HITEMS) {
+                    const int r = it % C::QR, rest = it / C::QR, u = rest % PR, cb = rest / PR;
+                    fir_block<NW, C::CB>(lds + u * C::PPL + (cb * C::CB) * C::QP + r, C::QP, sep.hc, hres[rd]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rd = 0; rd < C::HROUNDS; rd++) {
+                const int it = tid + rd * NT;
+                if (it < C::HITEMS) {
+                    const int r = it % C::QR, rest = it / C::QR, u = rest % PR, cb = rest / PR;
+                    double* dst = lds + u * C::PPL + (cb * C::CB) * C::QP + r;
+#pragma unroll
+                    for (int o = 0; o < C::CB; o++) dst[o * C::QP] = hres[rd][o];
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // V stage (along rows) and store: items (plane, rb, column), column fastest: the lanes of a 32-lane group read
         // 32 columns at the odd pitch QP (16 columns x two row blocks 16 rows apart on 16-column tiles): no bank is met
         // twice.  Two lanes with adjacent columns then swap half of their rows (DPP) so that each writes 16-byte table
@@ -367,7 +498,8 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
                 const int P = f * PR + pl, g = P / UB, u = P - g * UB;
                 if (P < C::NPL && u < nu && oi0 + g <= ms - 1) {
                     double out[C::CB];
-                    fir_block<NW, C::CB>(lds + pl * C::PPL + c * C::QP + rb * C::CB, 1, sep.hr, out);
+                    if constexpr (RO > 1) fir_running<NW, C::CB>(vsrc + pl * vpitch + c * C::HQP + rb * C::CB, 1, sep.hr, out);
+                    else fir_block<NW, C::CB>(vsrc + pl * vpitch + c * C::QP + rb * C::CB, 1, sep.hr, out);
                     const int ui = A.sigma * (oi0 + g), uj = A.sigma * (oj0 + u);
                     const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
                     const int col = pcol0 + c;
@@ -418,21 +550,21 @@ __device__ __forceinline__ void od_mark_done(const OdCorr& od, int lin, int pass
 }
 
 // One workgroup = one (tile, pass): a pass is UI consecutive row offsets and one batch of UB column offsets.
-template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF, int RO>
 __global__ void __launch_bounds__(NTG * UI, (NTG * UI / 64 * WPC + 3) / 4)
 corr_volume_kernel(ModelDev m, CorrArgs A, Sep1D sep, OdCorr od)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int UJ = 2 * m.ms - 1, npass = ((UJ + UI - 1) / UI) * ((UJ + UB - 1) / UB);
+    const int UJ = 2 * m.ms - 1, npass = ((UJ + UI * RO - 1) / (UI * RO)) * ((UJ + UB - 1) / UB);
     int lin, pass;
     if (!od_static_item(od, A.ntx, A.ntx * A.nty, npass, lin, pass)) return;
-    corr_volume_tile<NW, UB, TC, NTG, UI, WPC, NF>(m, A, sep, reinterpret_cast<double*>(smem_raw), lin, pass, threadIdx.x);
+    corr_volume_tile<NW, UB, TC, NTG, UI, WPC, NF, RO>(m, A, sep, reinterpret_cast<double*>(smem_raw), lin, pass, threadIdx.x);
     od_mark_done(od, lin, pass);
 }
 
 // The same over a work list of (tile, pass) pairs, by a persistent grid (the predicted passes and the repair rounds of
 // umpa_ondemand.h).  The body is a call in a loop: written out inside the loop it needed more registers than there are.
-template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF, int RO>
 __global__ void __launch_bounds__(NTG * UI, (NTG * UI / 64 * WPC + 3) / 4)
 corr_volume_queue_kernel(ModelDev m, CorrArgs A, Sep1D sep, OdCorr od)
 {
@@ -445,7 +577,7 @@ corr_volume_queue_kernel(ModelDev m, CorrArgs A, Sep1D sep, OdCorr od)
         if (idx < 0) break;
         const int it = __builtin_amdgcn_readfirstlane(gp(od.items)[idx]);
         if (j) __syncthreads();                                       // the previous item's last LDS reads
-        corr_volume_tile<NW, UB, TC, NTG, UI, WPC, NF>(m, A, sep, reinterpret_cast<double*>(smem_raw), it >> 8, it & 255, tid);
+        corr_volume_tile<NW, UB, TC, NTG, UI, WPC, NF, RO>(m, A, sep, reinterpret_cast<double*>(smem_raw), it >> 8, it & 255, tid);
         od_mark_done(od, it >> 8, it & 255);
     }
 }

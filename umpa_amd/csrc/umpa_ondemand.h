@@ -50,6 +50,7 @@ struct OdArgs {
     int tc, ub, nbatch, npass, ntx, nty;   // pass / tile geometry of the table kernel
     int r0, c0;                       // seed tiles: ty % OD_SP == r0 and tx % OD_SP == c0
     int ub_inv;                       // ceil(2^16 / ub): x / ub = (x * ub_inv) >> 16 for 0 <= x < 70
+    int nrow_inv;                     // the same for the row offsets per pass
     int nearest;                      // prediction: 1 what the nearest seed tile visited, 0 the union over the (up to four) seed tiles around
 };
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ bool od_is_seed(const OdArgs& od, int ty, int tx)
 __device__ __forceinline__ int od_pass_of(const OdArgs& od, int ms, int sigma, int si, int sj)
 {
     const int oi = (sigma > 0 ? si : -si) + ms - 1, oj = (sigma > 0 ? sj : -sj) + ms - 1;
-    return __mul24(oi, od.nbatch) + (__mul24(oj, od.ub_inv) >> 16);
+    return __mul24(__mul24(oi, od.nrow_inv) >> 16, od.nbatch) + (__mul24(oj, od.ub_inv) >> 16);
 }
 
 // the passes in `mask` of tile `lin` onto the work list (the passes of a tile stay together: they share their patches in L2)

@@ -519,7 +519,7 @@ inline OdCorr od_corr_args(const OdArgs& od)
 struct CorrLaunch {
     OdArgs od;                // od.mode 0: every pass (static grid); 3: seed tiles (compact static grid); 2: queue over od.items
     bool dry;                 // only report the geometry
-    int tc, ub, nbatch, npass, ntx, nty;   // out: tile columns, column offsets per pass, ... of the shape that was picked
+    int tc, ub, nrow, nbatch, npass, ntx, nty;   // out: tile columns, column / row offsets per pass, ... of the shape that was picked
     double fma_per_pass;      // out: fp64 FMAs one (tile, pass) executes (roofline accounting)
 };
 
@@ -536,17 +536,17 @@ inline int device_cu_count()
     return n[devid & 63];
 }
 
-template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF>
+template <int NW, int UB, int TC, int NTG, int UI, int WPC, int NF, int RO = 1>
 inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
-    using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>;
+    using C = CorrCfg<NW, UB, TC, NTG, UI, WPC, NF, RO>;
     A.ntx = (A.N1 + TC - 1) / TC;
     A.nty = (A.rows + C::TR - 1) / C::TR;
-    const int UJ = 2 * dev.ms - 1, nbatch = (UJ + UB - 1) / UB, npass = ((UJ + UI - 1) / UI) * nbatch;
-    L.tc = TC; L.ub = UB; L.nbatch = nbatch; L.npass = npass; L.ntx = A.ntx; L.nty = A.nty;
+    const int UJ = 2 * dev.ms - 1, nbatch = (UJ + UB - 1) / UB, npass = ((UJ + C::NROW - 1) / C::NROW) * nbatch;
+    L.tc = TC; L.ub = UB; L.nrow = C::NROW; L.nbatch = nbatch; L.npass = npass; L.ntx = A.ntx; L.nty = A.nty;
     // fp64 FMAs of one (tile, pass): the products of the active threads over all frames, the column filter on QR rows
     // and the row filter on the tile, for every plane of the pass (roofline accounting)
-    L.fma_per_pass = (double)C::QR * C::NQB * C::QB * UB * UI * dev.Na +
+    L.fma_per_pass = (double)C::QR * C::NQB * C::QB * UB * C::NROW * dev.Na +
                      (double)C::NPL * C::QR * TC * C::S + (double)C::NPL * C::TR * TC * C::S;
     if (L.dry) return hipSuccess;
     static bool attr_set[64] = {};                                    // the attribute is per device
@@ -555,7 +555,7 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
     {
         std::lock_guard<std::mutex> lock(tiled_attr_mutex());
         if (!attr_set[devid & 63]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF, RO>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
             if (e != hipSuccess) return e;
             attr_set[devid & 63] = true;
@@ -567,18 +567,18 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
         {
             std::lock_guard<std::mutex> lock(tiled_attr_mutex());
             if (!qattr_set[devid & 63]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_queue_kernel<NW, UB, TC, NTG, UI, WPC, NF>),
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_volume_queue_kernel<NW, UB, TC, NTG, UI, WPC, NF, RO>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
                 if (e != hipSuccess) return e;
                 qattr_set[devid & 63] = true;
             }
         }
         const int grid = ((device_cu_count() * WPC + 7) / 8) * 8;
-        hipLaunchKernelGGL((corr_volume_queue_kernel<NW, UB, TC, NTG, UI, WPC, NF>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
+        hipLaunchKernelGGL((corr_volume_queue_kernel<NW, UB, TC, NTG, UI, WPC, NF, RO>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
     } else {
         const int nt = L.od.mode == 3 ? oc.nseed : A.ntx * A.nty;
         const int grid = 8 * ((nt + 7) / 8) * npass;
-        if (nt > 0) hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
+        if (nt > 0) hipLaunchKernelGGL((corr_volume_kernel<NW, UB, TC, NTG, UI, WPC, NF, RO>), dim3(grid), dim3(C::NT), C::LDS, s, dev, A, sep, oc);
     }
     return hipGetLastError();
 }
@@ -601,14 +601,15 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // (planes to LDS 3.5 k, column filter 5.2 k, write back 2.5 k, row filter + stores 9.6 k).
 // (round 3: 32x32 / 512 threads (4 columns per product thread) / TWO per CU, two or three flush rounds: 1.72-1.73 against 1.70 for
 // shape 1 on the same box -- twice the waves change nothing: the kernel is not short of waves)
-#define UMPA_CORR_SHAPES(X) X(1, 32, 256, 1, 2, 2) X(2, 24, 256, 1, 2, 2) X(3, 16, 256, 1, 2, 1) X(4, 32, 512, 1, 1, 2)
+#define UMPA_CORR_SHAPES(X) X(5, 32, 512, 1, 1, 9, 3) X(1, 32, 256, 1, 2, 2, 1) X(2, 24, 256, 1, 2, 2, 1) X(3, 16, 256, 1, 2, 1, 1) X(4, 32, 512, 1, 1, 2, 1)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     const int want = tiled_corr_shape();
-#define UMPA_TRY_SHAPE(id, TC, NTG, UI, WPC, NF)                                                        \
-    if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, NF>::OK) {                                          \
-        if (want == 0 || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF>(dev, A, sep, s, L);  \
+    const bool ro_pays = (2 * dev.ms - 1) % 3 == 0;                   // three row offsets per pass: no idle third pass
+#define UMPA_TRY_SHAPE(id, TC, NTG, UI, WPC, NF, RO)                                                    \
+    if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, NF, RO>::OK && (RO == 1 || (NW == 5 && UB == 9))) {     \
+        if ((want == 0 && (RO == 1 || ro_pays)) || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF, RO>(dev, A, sep, s, L);  \
     }
     UMPA_CORR_SHAPES(UMPA_TRY_SHAPE)
 #undef UMPA_TRY_SHAPE
@@ -923,7 +924,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         OdArgs od;
         memset(&od, 0, sizeof(od));
         od.tc = CL.tc; od.ub = CL.ub; od.nbatch = CL.nbatch; od.npass = CL.npass; od.ntx = CL.ntx; od.nty = CL.nty;
-        od.ub_inv = (65536 + CL.ub - 1) / CL.ub;
+        od.ub_inv = (65536 + CL.ub - 1) / CL.ub; od.nrow_inv = (65536 + CL.nrow - 1) / CL.nrow;
         OdBuffers OB;
         if (od_enabled(ntiles, CL.npass, false) && !CA.ablate) {
             if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
@@ -980,7 +981,7 @@ inline hipError_t launch_masked_tc(const ModelDev& dev, MaskedArgs A, const Sep1
         A.ntx = (A.N1 + C::TC - 1) / C::TC;
         A.nty = (A.rows + C::TR - 1) / C::TR;
         const int UJ = 2 * dev.ms - 1, nbatch = (UJ + UBM - 1) / UBM, npass = UJ * nbatch;
-        L.tc = C::TC; L.ub = UBM; L.nbatch = nbatch; L.npass = npass; L.ntx = A.ntx; L.nty = A.nty;
+        L.tc = C::TC; L.ub = UBM; L.nrow = 1; L.nbatch = nbatch; L.npass = npass; L.ntx = A.ntx; L.nty = A.nty;
         // fp64 issue slots (FMA, multiply or add each counted once) of one (tile, pass) with UBM column offsets: per frame
         // and column offset the products of the active threads (pair weight 6 + 7) and, DF, three planes through both
         // filters + the fold into t2, t4, t6, wt; at the end NPL planes through both filters and the solve
@@ -1158,7 +1159,7 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
         OdArgs od;
         memset(&od, 0, sizeof(od));
         od.tc = CL.tc; od.ub = CL.ub; od.nbatch = CL.nbatch; od.npass = CL.npass; od.ntx = CL.ntx; od.nty = CL.nty;
-        od.ub_inv = (65536 + CL.ub - 1) / CL.ub;
+        od.ub_inv = (65536 + CL.ub - 1) / CL.ub; od.nrow_inv = (65536 + CL.nrow - 1) / CL.nrow;
         OdBuffers OB;
         if (od_enabled(ntiles, CL.npass, true) && !MA.ablate) {
             if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
