@@ -601,6 +601,10 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // (planes to LDS 3.5 k, column filter 5.2 k, write back 2.5 k, row filter + stores 9.6 k).
 // (round 3: 32x32 / 512 threads (4 columns per product thread) / TWO per CU, two or three flush rounds: 1.72-1.73 against 1.70 for
 // shape 1 on the same box -- twice the waves change nothing: the kernel is not short of waves)
+// Shape 5 (round 3): 32x32 tiles / 512 threads / ONE per CU, every product thread accumulates THREE row offsets from one
+// staging (RO = 3, 4 columns x UB offsets x 3 = up to 108 accumulators of the 128 a thread can hold), flush in rounds of three
+// planes (as many rounds as column offsets).  A third of the L2 -> LDS traffic per plane: C2 1.64-1.72 -> 1.31-1.45 (same
+// boxes).  Taken when 2 max_shift - 1 is a multiple of three (no idle third pass) and the window is at most 13 wide.
 #define UMPA_CORR_SHAPES(X) X(5, 32, 512, 1, 1, 9, 3) X(1, 32, 256, 1, 2, 2, 1) X(2, 24, 256, 1, 2, 2, 1) X(3, 16, 256, 1, 2, 1, 1) X(4, 32, 512, 1, 1, 2, 1)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
@@ -608,8 +612,9 @@ inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, cons
     const int want = tiled_corr_shape();
     const bool ro_pays = (2 * dev.ms - 1) % 3 == 0;                   // three row offsets per pass: no idle third pass
 #define UMPA_TRY_SHAPE(id, TC, NTG, UI, WPC, NF, RO)                                                    \
-    if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, NF, RO>::OK && (RO == 1 || (NW == 5 && UB == 9))) {     \
-        if ((want == 0 && (RO == 1 || ro_pays)) || want == id) return launch_corr<NW, UB, TC, NTG, UI, WPC, NF, RO>(dev, A, sep, s, L);  \
+    if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, (RO > 1 ? UB : NF), RO>::OK) {                         \
+        if ((want == 0 && (RO == 1 || ro_pays)) || want == id)                                              \
+            return launch_corr<NW, UB, TC, NTG, UI, WPC, (RO > 1 ? UB : NF), RO>(dev, A, sep, s, L);          \
     }
     UMPA_CORR_SHAPES(UMPA_TRY_SHAPE)
 #undef UMPA_TRY_SHAPE
