@@ -299,12 +299,79 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     return UMPA_ST_OK;
 }
 
+// The same evaluation in three pieces for the frame-count templates (NA > 0), so that a caller can have the loads of TWO
+// evaluations in flight before it waits for either (replay_walk's speculative second lookup): status, loads, solve.
+// lookup_solve repeats eval_lookup's arithmetic expression by expression: the numbers are the same.
+__device__ __forceinline__ int lookup_status(int ms, int si, int sj)
+{
+    if (si <= -ms || si >= ms) return UMPA_ST_BOUND;
+    if (sj <= -ms) return UMPA_ST_BOUND | UMPA_ST_DIM;
+    if (sj >= ms) return UMPA_ST_BOUND | UMPA_ST_DIM | UMPA_ST_POSITIVE;
+    return UMPA_ST_OK;
+}
+
+template <int NA>
+struct LookupRaw {
+    double t5, sq;                                                  // table entry; SamSq ('ref' mode) or RefSq at the moving window
+    map_pair_t mp[NA > 0 ? (NA + 1) / 2 : 1];                       // the moving per-frame maps (dark-field model)
+};
+
+template <int KIND, int NA>
+__device__ __forceinline__ void lookup_load(const ModelDev& m, const Maps& M, const ReplayArgs& R, int ref_mode,
+                                            int i, int j, size_t tpx, int si, int sj, LookupRaw<NA>& raw)   // |si|, |sj| < ms
+{
+    const int ms = m.ms, UJ = 2 * ms - 1;
+    const unsigned slot = (unsigned)((si + ms - 1) * UJ + (sj + ms - 1));
+    raw.t5 = gp(R.table)[(size_t)slot * (unsigned)R.slot_stride + tpx];
+    const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
+    const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
+    raw.sq = ref_mode ? ld_off(gp(M.SamSq), (unsigned)xs * 8u) : ld_off(gp(M.RefSq), (unsigned)xr * 8u);
+    if (KIND == 1) {
+        const size_t plane = (size_t)M.H * M.W;
+        const unsigned bm = (unsigned)(ref_mode ? xs : xr) * 16u;
+        const UMPA_GLOBAL double* __restrict__ mov = gp(ref_mode ? M.WS : M.MR);
+#pragma unroll
+        for (int q = 0; q < (NA + 1) / 2; q++) raw.mp[q] = ld_pair_off(mov + (size_t)q * 2 * plane, bm);
+    }
+}
+
+template <int KIND, int NA>
+__device__ __forceinline__ void lookup_solve(const ModelDev& m, int ref_mode, const LookupRaw<NA>& raw,
+                                             const double* fixed, const PixConst& pc, double& cost, Fit& fit)
+{
+    const double t5 = raw.t5;
+    const double rwt = 1.0 / (double)m.Na;
+    double t1 = pc.t1, t3 = pc.t3;
+    if (ref_mode) t1 = raw.sq; else t3 = raw.sq;
+    if (KIND == 1) {
+        double t2 = 0.0, t4 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NA; k++) { const double a = raw.mp[k >> 1][k & 1]; t4 = fma(a, fixed[k], t4); t2 = fma(a, a, t2); }
+        double t6;
+        if (ref_mode) { t2 = pc.t2; t6 = pc.t6; }
+        else t6 = m.win_sum * t2;
+        const double rdet = fast_rcp(t2 * t3 - t6 * t6);
+        const double K = (t2 * t5 - t4 * t6) * rdet;
+        const double beta = (t3 * t4 - t5 * t6) * rdet;
+        fit.t = beta + K;
+        fit.v = K;
+        cost = (t1 + beta * beta * t2 + K * K * t3 - 2 * beta * t4 - 2 * K * t5 + 2 * beta * K * t6) * rwt;
+    } else {
+        fit.t = t5 / t3;
+        fit.v = 0.0;
+        cost = (t1 - t5 * fit.t) * rwt;
+    }
+}
+
 // Workgroup = UMPA_REPLAY_ROWS waves, each on 64 consecutive pixels of one row.  A workgroup keeps its LDS until
 // its slowest wave has finished, so small workgroups refill the CU sooner (the walk lengths differ).
 #ifndef UMPA_REPLAY_ROWS
 #define UMPA_REPLAY_ROWS 1
 #endif
 #define UMPA_REPLAY_THREADS (64 * UMPA_REPLAY_ROWS)
+#ifndef UMPA_REPLAY_SPECULATE
+#define UMPA_REPLAY_SPECULATE 1
+#endif
 
 // OD = false: the plain kernel (every table plane is there): the on-demand bookkeeping compiles away (it costs 20 VGPRs and
 // 0.1 ms on C2 otherwise)
@@ -393,8 +460,28 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         if (!od_check(od, L, m.ms, sigma, w.req_i, w.req_j)) break;  // the plane is not there: this pixel is parked
         double c = 0.0;
         Fit fit = w.live;
-        const int st = eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, pc, c, fit);
-        walk_feed(w, memo, st, c, fit, m.call_cap);
+        if constexpr (!OD && NA > 0 && UMPA_REPLAY_SPECULATE) {
+            // the walk is a chain of dependent lookups, each a round trip to the table: the request that will follow is
+            // looked up beside the pending one (walk_speculate) and delivered if the walk then asks for it.  Straight-line
+            // code: lanes without a (valid) second request repeat the first one's addresses, a request outside the search
+            // range loads shift (0, 0) and is answered by its status alone.
+            int si = w.req_i, sj = w.req_j;
+            const bool spec = walk_speculate(w, si, sj);
+            const int st = lookup_status(m.ms, w.req_i, w.req_j), st2 = lookup_status(m.ms, si, sj);
+            const bool ok1 = st == UMPA_ST_OK, ok2 = st2 == UMPA_ST_OK;
+            LookupRaw<NA> r1, r2;
+            lookup_load<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, ok1 ? w.req_i : 0, ok1 ? w.req_j : 0, r1);
+            lookup_load<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, ok2 ? si : 0, ok2 ? sj : 0, r2);
+            double c2 = 0.0;
+            Fit fit2 = w.live;
+            lookup_solve<KIND, NA>(m, m.ref_mode, r1, fixed, pc, c, fit);
+            lookup_solve<KIND, NA>(m, m.ref_mode, r2, fixed, pc, c2, fit2);
+            walk_feed(w, memo, st, c, fit, m.call_cap);
+            if (spec && w.phase < PH_FIT && w.req_i == si && w.req_j == sj) walk_feed(w, memo, st2, c2, fit2, m.call_cap);
+        } else {
+            const int st = eval_lookup<KIND, NA>(m, M, R, m.ref_mode, i, j, tpx, w.req_i, w.req_j, fixed, pc, c, fit);
+            walk_feed(w, memo, st, c, fit, m.call_cap);
+        }
     }
     if (L.miss) od_park(od, L, (int)px);
     else {
@@ -906,9 +993,10 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
             dim3 blk(64, UMPA_REPLAY_ROWS), grd((A.N1 + 63) / 64, (R.rows + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
             if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);   // queue over the parked pixels
             if (od.mode == 1) { blk = dim3(64, 1); grd = dim3((32 * od.tc + 63) / 64, od_seed_count(od.ntx, od.c0) * od_seed_count(od.nty, od.r0)); if (!grd.y) return hipSuccess; }
+            static const int pad_lds = getenv("UMPA_HIP_REPLAY_PAD_LDS") ? atoi(getenv("UMPA_HIP_REPLAY_PAD_LDS")) : 0;   // diagnostics: occupancy
             tic(4);
-#define UMPA_REPLAY_NA(n) case n: if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<1, n, true>), grd, blk, 0, s, dev, M, R, A, od); \
-                           else hipLaunchKernelGGL((replay_walk_kernel<1, n, false>), grd, blk, 0, s, dev, M, R, A, od); break;
+#define UMPA_REPLAY_NA(n) case n: if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<1, n, true>), grd, blk, pad_lds, s, dev, M, R, A, od); \
+                           else hipLaunchKernelGGL((replay_walk_kernel<1, n, false>), grd, blk, pad_lds, s, dev, M, R, A, od); break;
             if (kind == 1 && small && dev.Na <= UMPA_KTEMPL) {
                 switch (dev.Na) {
                     UMPA_REPLAY_NA(1) UMPA_REPLAY_NA(2) UMPA_REPLAY_NA(3) UMPA_REPLAY_NA(4) UMPA_REPLAY_NA(5) UMPA_REPLAY_NA(6)
@@ -917,10 +1005,10 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
                     UMPA_REPLAY_NA(19) UMPA_REPLAY_NA(20) UMPA_REPLAY_NA(21) UMPA_REPLAY_NA(22) UMPA_REPLAY_NA(23) UMPA_REPLAY_NA(24)
                 }
             } else if (kind == 1) {
-                if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<1, 0, true>), grd, blk, 0, s, dev, M, R, A, od);
-                else hipLaunchKernelGGL((replay_walk_kernel<1, 0, false>), grd, blk, 0, s, dev, M, R, A, od);
-            } else if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<0, 0, true>), grd, blk, 0, s, dev, M, R, A, od);
-            else hipLaunchKernelGGL((replay_walk_kernel<0, 0, false>), grd, blk, 0, s, dev, M, R, A, od);
+                if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<1, 0, true>), grd, blk, pad_lds, s, dev, M, R, A, od);
+                else hipLaunchKernelGGL((replay_walk_kernel<1, 0, false>), grd, blk, pad_lds, s, dev, M, R, A, od);
+            } else if (od.mode) hipLaunchKernelGGL((replay_walk_kernel<0, 0, true>), grd, blk, pad_lds, s, dev, M, R, A, od);
+            else hipLaunchKernelGGL((replay_walk_kernel<0, 0, false>), grd, blk, pad_lds, s, dev, M, R, A, od);
 #undef UMPA_REPLAY_NA
             toc();
             return hipGetLastError();

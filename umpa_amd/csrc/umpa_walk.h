@@ -341,6 +341,38 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
     w.phase = PH_FIT;
 }
 
+// The request that will follow the pending one -- where that is known before the pending one's cost is (the high neighbour
+// after the low one, the next cell of the gather), or a guess (a walk that just stepped along an axis often steps again).
+// A caller may evaluate it beside the pending request (two independent chains of loads instead of one) and deliver it
+// with walk_feed if, after the pending result has been delivered, the walk does ask for exactly this shift; otherwise the
+// value is dropped.  The walk itself is untouched: which costs it sees, in which order, and Ncalls stay the reference's.
+__device__ inline bool walk_speculate(const Walk& w, int& si, int& sj)
+{
+    const int di = w.axis ? 1 : 0, dj = w.axis ? 0 : 1;
+    if (w.phase == PH_CENTRE) {                                 // then the low neighbour (nothing else is known at the start)
+        si = w.ci - di; sj = w.cj - dj;
+        return true;
+    }
+    if (w.phase == PH_LO) {
+        const int hr = w.axis ? 3 : 2, hc = w.axis ? 2 : 3;
+        if (!((w.known >> (5 * hr + hc)) & 1u)) { si = w.ci + di; sj = w.cj + dj; }   // the high neighbour follows in any case
+        else { si = w.req_i - di; sj = w.req_j - dj; }          // guess: the walk steps down and asks for the cell beyond
+        return true;
+    }
+    if (w.phase == PH_HI) {                                     // guess: the walk steps up and asks for the cell beyond
+        si = w.req_i + di; sj = w.req_j + dj;
+        return true;
+    }
+    if (w.phase == PH_GATHER) {
+        const unsigned rest = w.need & (w.need - 1);
+        if (!rest) return false;
+        const int g = __ffs(rest) - 1;
+        si = w.ci + w.ip + (g >> 2) - 2; sj = w.cj + w.jp + (g & 3) - 2;
+        return true;
+    }
+    return false;
+}
+
 // Sub-pixel refinement for the lanes whose walk completed (Optim.cpp:386-410).  `nb` receives the
 // 4x4 neighbourhood (minimizer_debug::a); it is the (ip,jp) sub-block of the memo.
 template <class Memo>
