@@ -145,7 +145,7 @@ struct CorrCfg {
     static constexpr int HITEMS = PR * (TC / CB) * QR, HROUNDS = (HITEMS + NT - 1) / NT;
     static constexpr bool OK = NSLOT >= 2 && FLUSH * 8 <= LDSB && QR * NQB <= NTG && (NSLOT - 1) * NPT < 64 &&
                                LDS_DOUBLES * 8 <= LDSB && NTG % 64 == 0 && NT <= 1024 && WPS <= 8 && (RO == 1 || UI == 1) &&
-                               QB * UB * RO <= 112;
+                               QB * UB * RO <= (QB == 4 ? 112 : 100);
 };
 
 // 16-byte store of two table entries, non-temporal (`nt`): the 2.7 GB streaming out no longer push the frame patches

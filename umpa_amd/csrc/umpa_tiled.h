@@ -372,6 +372,9 @@ __device__ __forceinline__ void lookup_solve(const ModelDev& m, int ref_mode, co
 #ifndef UMPA_REPLAY_SPECULATE
 #define UMPA_REPLAY_SPECULATE 1
 #endif
+// two evaluations in flight hold two sets of per-frame map values: beyond this many frames the registers run out (12: spills)
+// (20 frames, C3: 8.7 -> 20.6 ms with the second lookup)
+#define UMPA_REPLAY_SPECULATE_NA 11
 
 // OD = false: the plain kernel (every table plane is there): the on-demand bookkeeping compiles away (it costs 20 VGPRs and
 // 0.1 ms on C2 otherwise)
@@ -460,7 +463,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         if (!od_check(od, L, m.ms, sigma, w.req_i, w.req_j)) break;  // the plane is not there: this pixel is parked
         double c = 0.0;
         Fit fit = w.live;
-        if constexpr (!OD && NA > 0 && UMPA_REPLAY_SPECULATE) {
+        if constexpr (!OD && NA > 0 && NA <= UMPA_REPLAY_SPECULATE_NA && UMPA_REPLAY_SPECULATE) {
             // the walk is a chain of dependent lookups, each a round trip to the table: the request that will follow is
             // looked up beside the pending one (walk_speculate) and delivered if the walk then asks for it.  Straight-line
             // code: lanes without a (valid) second request repeat the first one's addresses, a request outside the search
@@ -697,10 +700,13 @@ template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     const int want = tiled_corr_shape();
-    const bool ro_pays = (2 * dev.ms - 1) % 3 == 0;                   // three row offsets per pass: no idle third pass
+    const bool ro3_pays = (2 * dev.ms - 1) % 3 == 0;                  // three row offsets per pass: no idle third pass
+    // (two row offsets per pass, 384 threads with 6 columns each -- the window of C3 does not fit the 512 x 4-column shape:
+    //  C3 35.8 -> 34.3 ms; not kept, 4 % do not pay for another set of instantiations)
+    const bool ro2_pays = false;
 #define UMPA_TRY_SHAPE(id, TC, NTG, UI, WPC, NF, RO)                                                    \
     if constexpr (CorrCfg<NW, UB, TC, NTG, UI, WPC, (RO > 1 ? UB : NF), RO>::OK) {                         \
-        if ((want == 0 && (RO == 1 || ro_pays)) || want == id)                                              \
+        if ((want == 0 && (RO == 1 || (RO == 3 && ro3_pays) || (RO == 2 && ro2_pays))) || want == id)       \
             return launch_corr<NW, UB, TC, NTG, UI, WPC, (RO > 1 ? UB : NF), RO>(dev, A, sep, s, L);          \
     }
     UMPA_CORR_SHAPES(UMPA_TRY_SHAPE)

@@ -346,6 +346,9 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
 // A caller may evaluate it beside the pending request (two independent chains of loads instead of one) and deliver it
 // with walk_feed if, after the pending result has been delivered, the walk does ask for exactly this shift; otherwise the
 // value is dropped.  The walk itself is untouched: which costs it sees, in which order, and Ncalls stay the reference's.
+#ifndef UMPA_WALK_GUESS
+#define UMPA_WALK_GUESS 1
+#endif
 __device__ inline bool walk_speculate(const Walk& w, int& si, int& sj)
 {
     const int di = w.axis ? 1 : 0, dj = w.axis ? 0 : 1;
@@ -356,10 +359,12 @@ __device__ inline bool walk_speculate(const Walk& w, int& si, int& sj)
     if (w.phase == PH_LO) {
         const int hr = w.axis ? 3 : 2, hc = w.axis ? 2 : 3;
         if (!((w.known >> (5 * hr + hc)) & 1u)) { si = w.ci + di; sj = w.cj + dj; }   // the high neighbour follows in any case
-        else { si = w.req_i - di; sj = w.req_j - dj; }          // guess: the walk steps down and asks for the cell beyond
+        else if (UMPA_WALK_GUESS) { si = w.req_i - di; sj = w.req_j - dj; }   // guess: the walk steps down and asks for the cell beyond
+        else return false;
         return true;
     }
     if (w.phase == PH_HI) {                                     // guess: the walk steps up and asks for the cell beyond
+        if (!UMPA_WALK_GUESS) return false;                     // (choosing the side by the low neighbour's cost: measured slower)
         si = w.req_i + di; sj = w.req_j + dj;
         return true;
     }
