@@ -516,13 +516,13 @@ def bench_c5(device=0, steps=1, warmup=1, n_proj=32, raw_dtype=np.uint16, keep=N
 
     kept = {}
 
-    def series():
+    def series(keep_now=False):
         nonlocal ok
         n, last = 0, None
         for pid, res in sm.run(((p, bufs[p]) for p in range(n_proj))):
             n += 1
             last = res                                              # the consumer of this bench only counts
-            if keep is not None and pid == keep:
+            if keep_now and pid == keep:
                 kept["res"] = {k: np.array(v) for k, v in res.items() if isinstance(v, np.ndarray)}
         ok = float(last["err"].mean())
         return n
@@ -534,6 +534,8 @@ def bench_c5(device=0, steps=1, warmup=1, n_proj=32, raw_dtype=np.uint16, keep=N
         done = series()
     dt = (time.perf_counter() - t0) / steps
     assert done == n_proj
+    if keep is not None:
+        series(keep_now=True)                                       # one more pass, untimed: the 181 MB copy of the kept maps stays out of the rate
     in_bytes = K * H * W * np.dtype(raw_dtype).itemsize
     out_bytes = N0 * N1 * (5 * 8 + 4)
     line = {
