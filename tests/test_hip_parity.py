@@ -327,6 +327,46 @@ def test_sample_stepping_on_the_tiled_path(hip_ns, port_ns, variant):
     np.testing.assert_array_equal(g.coverage(), o.coverage())
 
 
+@pytest.mark.parametrize("df,assign", [(True, "sam"), (False, "ref"), (True, "ref")])
+def test_sample_stepping_border_rectangles_on_the_tiled_path(hip_ns, port_ns, df, assign):
+    """A 2 x 2 grid of positions: the region falls into rectangles with a constant set of contributing frames.  The large
+    ones (the centre with every frame, the four edges with half of them, the corners with a quarter) each run on the tiled
+    path with their subset's frames -- the cost still divided by the model's frame count --, the slivers (a frame's last
+    contributing column, small rectangles) on the general kernels.  Against the CPU oracle, with a coverage threshold."""
+    import ctypes
+    from umpa_amd.synth import make_stack
+    Nw, ms, K = 2, 3, 8
+    pos = [np.array(p) for p in [(0, 0), (0, 150), (120, 0), (120, 150), (0, 0), (120, 150), (0, 150), (120, 0)]]
+    frames = [make_stack(330, 380, 1, ms, df=True, seed=500 + k, amplitude=1.5) for k in range(K)]
+    sam = [np.ascontiguousarray(f[0][0]) for f in frames]
+    ref = [np.ascontiguousarray(f[1][0]) for f in frames]
+    kw = dict(window_size=Nw, max_shift=ms, pos_list=pos)
+    name = "UMPAModelDF" if df else "UMPAModelNoDF"
+    g, o = getattr(hip_ns, name)(sam, ref, **kw), getattr(port_ns, name)(sam, ref, **kw)
+    g.assign_coordinates = o.assign_coordinates = assign
+    lib, h = g._lib, g._handle
+    lib.timing_enable(h, 1)
+    got, want = g.match(quiet=True), o.match(quiet=True)
+    assert lib.last_path(h) == 4
+    launches = {}
+    for q in range(lib.timing_collect(h)):
+        nm, tot, cnt = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int()
+        lib.timing_read(h, q, ctypes.byref(nm), ctypes.byref(tot), ctypes.byref(cnt))
+        launches[nm.value.decode()] = cnt.value
+    lib.timing_enable(h, 0)
+    assert launches.get("corr_volume", 0) >= 9, launches           # centre + 4 edges + 4 corners
+    st = assert_parity(got, want, ms, "stepping rectangles %s %s" % (name, assign))
+    assert st["ok"] > 100000
+    # the same through a ROI with steps and a start shift (the rectangles move with the region's origin and step)
+    mk = dict(quiet=True, ROI=((3, 400, 2), (5, 480, 1)), dxdy=(1, -1))
+    got, want = g.match(**mk), o.match(**mk)
+    assert_parity(got, want, ms, "stepping rectangles ROI %s %s" % (name, assign))
+    # a second match of the same model takes the cached descriptor lists
+    got2 = g.match(**mk)
+    for k in ("f", "dx", "dy", "T", "err"):
+        np.testing.assert_array_equal(got2[k], got[k])
+
+
 def test_plain_c_host_of_the_c_abi(hip_ns, tmp_path):
     """examples/c_host.c: the boundary is a C ABI -- a host with no Python and no PyTorch in the process."""
     import subprocess

@@ -27,6 +27,8 @@ struct ModelDev {
     const double* win;         // (2Nw+1)^2, device (ModelBase::win, Model.h:88)
     double win_sum;            // sum of win in row-major order (the `denom` of Model.cpp:724-739)
     int Na, Nw, ms, padding;
+    int Nwt;                   // the frame count the cost of a model without masks is divided by (Model.cpp:425, :711): the
+                               // model's, also where `frames` lists only the frames that contribute in a sub-rectangle
     int subpx, ref_mode;
     int call_cap;              // MAX_CALLS of Optim.cpp:14 (500; UMPA_CALL_CAP in the environment of the creating process
                                // lowers it for the tests that pin the behaviour at the cap)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
 #include <new>
 #include <cstdlib>
 #include <cmath>
@@ -71,6 +72,10 @@ struct umpa_hip_model {
     std::vector<double*> d_sam, d_ref, d_mask;     // device frame pointers
     void* d_frames_blob = nullptr;                 // one allocation holding all owned frames
     FrameDesc* d_desc = nullptr;
+    // sample stepping: descriptor lists of frame subsets (run_match), a ring in page-locked and device memory
+    struct SubList { std::vector<FrameDesc> host; int slot; };
+    std::map<unsigned, SubList> sub_lists;    // by frame bit mask: what the device slot holds
+    FrameDesc* d_sub = nullptr;
     double* d_win = nullptr;
     std::vector<double> win;
     double win_sum = 0.0;
@@ -114,7 +119,7 @@ struct umpa_hip_model {
     {
         ModelDev d;
         d.frames = d_desc; d.win = d_win; d.win_sum = win_sum;
-        d.Na = Na; d.Nw = Nw; d.ms = ms; d.padding = padding; d.subpx = subpx; d.ref_mode = ref_mode; d.call_cap = call_cap;
+        d.Na = Na; d.Nwt = Na; d.Nw = Nw; d.ms = ms; d.padding = padding; d.subpx = subpx; d.ref_mode = ref_mode; d.call_cap = call_cap;
         return d;
     }
 };
@@ -288,7 +293,7 @@ int run_direct(umpa_hip_model* m, const RegionArgs& A0, hipStream_t s, int flags
     // (with masks the staged kernel is the slower one -- three footprints leave room for one workgroup per CU and the
     // weights make the summation VALU-bound: 225 against 152 ms on C2 -- so masked models stay on match_direct)
     if (m->kind != UMPA_HIP_KIND_DFKERNEL && !m->has_mask && !no_staged && !(flags & UMPA_HIP_F_FORCE_PLAIN_DIRECT) &&
-        (size_t)A.N0 * A.N1 >= 64 && staged_geometry(m, A, G, lds_bytes)) {
+        (size_t)A.N0 * A.N1 >= 64 && A.N1 >= 8 && staged_geometry(m, A, G, lds_bytes)) {      // (a column or two: one lane per workgroup row would work)
         hipError_t e;
         // (no masked instantiation: masked models never come here -- above -- and run on the tiled path, umpa_masked.h)
         if (m->kind == UMPA_HIP_KIND_NODF) e = launch_staged<0, false>(m, A, G, lds_bytes, s);
@@ -404,6 +409,11 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A, bool forced 
 // kernels form).
 struct StepGeom { bool any_pos; int Himg, Wimg; FrameBox box; int a0, b0, a1, b1; };
 
+// corr_volume stages 16-byte column pairs: a pair that starts on a frame's last column reads 8 bytes past the end of the
+// row.  Frames the library owns are laid out back to back with 16 spare bytes at the end of the allocation, so those bytes
+// are readable (and never used); borrowed device frames give no such promise.  (corr_masked keeps its own clamp.)
+bool pair_slack(const umpa_hip_model* m) { return m->owns_frames && !m->has_mask; }
+
 StepGeom step_geometry(const umpa_hip_model* m, const RegionArgs& A)
 {
     StepGeom g;
@@ -422,7 +432,9 @@ StepGeom step_geometry(const umpa_hip_model* m, const RegionArgs& A)
     const int pad = m->padding;
     // (the last contributing column, j = c1 + 1 - pad, would make corr_volume read the very last column of a frame as the
     // first half of a 16-byte column pair: it is left to the border strip)
-    const int imin = r0 + pad, imax = r1 + 1 - pad, jmin = c0 + pad, jmax = c1 - pad;
+    // -- unless 8 readable bytes follow every frame (pair_slack: frames the library owns, models without masks)
+    g.box.slack = pair_slack(m) ? 1 : 0;
+    const int imin = r0 + pad, imax = r1 + 1 - pad, jmin = c0 + pad, jmax = c1 - pad + g.box.slack;
     auto lo = [](int vmin, int org, int step, int N) { int q = vmin - org; q = q <= 0 ? 0 : (q + step - 1) / step; return std::min(q, N); };
     auto hi = [](int vmax, int org, int step, int N) { int q = vmax - org; q = q < 0 ? 0 : q / step + 1; return std::min(q, N); };
     g.a0 = lo(imin, A.org0, A.step0, A.N0); g.b0 = std::max(g.a0, hi(imax, A.org0, A.step0, A.N0));
@@ -430,16 +442,24 @@ StepGeom step_geometry(const umpa_hip_model* m, const RegionArgs& A)
     return g;
 }
 
+// `sub`: the frames that contribute in this sub-rectangle of a sample-stepping stack (a descriptor list of its own, the box
+// of image rows / columns inside every one of them); NULL = all frames
+struct FrameSubset { const FrameDesc* frames; int n; FrameBox box; };
+
 int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int flags, hipStream_t s,
-              int piece_rows, const std::function<void(int, int)>& on_rows)
+              int piece_rows, const std::function<void(int, int)>& on_rows, const FrameSubset* sub = nullptr)
 {
     TiledTimers tt;
     tt.get = [m]() { return get_event(m); };
+    ModelDev dev = m->dev();
+    if (sub) { dev.frames = sub->frames; dev.Na = sub->n; m->tiled.ref_maps_ok = false; }      // (Nwt stays the model's frame count)
+    const bool reuse = !sub && (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0;
     int rc = m->has_mask
-        ? tiled_match_masked(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
-                             m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, m->mask_binary, piece_rows, on_rows)
-        : tiled_match(m->tiled, m->dev(), m->kind, g.Himg, g.Wimg, g.box, A, s,
-                      m->timing ? &tt : nullptr, (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0, piece_rows, on_rows);
+        ? tiled_match_masked(m->tiled, dev, m->kind, g.Himg, g.Wimg, g.box, A, s,
+                             m->timing ? &tt : nullptr, reuse, m->mask_binary, piece_rows, on_rows)
+        : tiled_match(m->tiled, dev, m->kind, g.Himg, g.Wimg, sub ? sub->box : g.box, A, s,
+                      m->timing ? &tt : nullptr, reuse, piece_rows, on_rows);
+    if (sub) m->tiled.ref_maps_ok = false;                            // the maps now hold a subset's planes
     if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
     if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
     for (const auto& en : tt.entries) { TimedLaunch tl; tl.name = en.name; tl.t0 = en.t0; tl.t1 = en.t1; tl.fma = en.fma; tl.counts = en.counts; tl.fma_per = en.fma_per; m->launches.push_back(tl); }
@@ -459,8 +479,9 @@ hipError_t copy_block(void* dst, int dN1, int dr, int dc, const void* src, int s
 // One sub-rectangle [r0,r1) x [c0,c1) of the region, matched into dense scratch arrays and copied back: `tiled` sends
 // it down the tiled path (every frame contributes everywhere in it), otherwise the general kernels take it.
 int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0, int r1, int c0, int c1, bool tiled,
-              int flags, hipStream_t s)
+              int flags, hipStream_t s, const FrameSubset* sub = nullptr)
 {
+    const bool keep_in = !tiled || sub != nullptr;                    // pixels the kernels may leave untouched: coverage threshold
     const int rows = r1 - r0, cols = c1 - c0;
     if (rows <= 0 || cols <= 0) return 0;
     const size_t n = (size_t)rows * cols, nfull = (size_t)A.N0 * A.N1;
@@ -477,18 +498,18 @@ int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0,
     auto in = [&](void* t, const void* full, size_t epp) { if (e == hipSuccess) e = copy_block(t, cols, 0, 0, full, A.N1, r0, c0, rows, cols, epp, s); };
     auto out = [&](void* full, const void* t, size_t epp) { if (e == hipSuccess) e = copy_block(full, A.N1, r0, c0, t, cols, 0, 0, rows, cols, epp, s); };
     // what the kernels may leave untouched (pixels below the coverage threshold) must come back as it was
-    if (!tiled) {
+    if (keep_in) {
         if (planar) for (int k = 0; k < np; k++) in(B.values + (size_t)k * n, A.values + (size_t)k * nfull, sizeof(double));
         else in(B.values, A.values, np * sizeof(double));
         in(B.err, A.err, sizeof(int));
     }
     if (A.uv) { if (m->t_uv.reserve(n * 2 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.uv = (double*)m->t_uv.p; in(B.uv, A.uv, 2 * sizeof(double)); }
-    if (A.cover && !tiled) { if (m->t_cover.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); in(m->t_cover.p, A.cover, sizeof(double)); B.cover = (const double*)m->t_cover.p; }
-    if (A.dbg_d) { if (m->t_dd.reserve(n * 25 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_d = (double*)m->t_dd.p; if (!tiled) in(B.dbg_d, A.dbg_d, 25 * sizeof(double)); }
-    if (A.dbg_a) { if (m->t_da.reserve(n * 16 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_a = (double*)m->t_da.p; if (!tiled) in(B.dbg_a, A.dbg_a, 16 * sizeof(double)); }
-    if (A.dbg_n) { if (m->t_dn.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_n = (int*)m->t_dn.p; if (!tiled) in(B.dbg_n, A.dbg_n, sizeof(int)); }
+    if (A.cover && keep_in) { if (m->t_cover.reserve(n * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); in(m->t_cover.p, A.cover, sizeof(double)); B.cover = (const double*)m->t_cover.p; }
+    if (A.dbg_d) { if (m->t_dd.reserve(n * 25 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_d = (double*)m->t_dd.p; if (keep_in) in(B.dbg_d, A.dbg_d, 25 * sizeof(double)); }
+    if (A.dbg_a) { if (m->t_da.reserve(n * 16 * sizeof(double))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_a = (double*)m->t_da.p; if (keep_in) in(B.dbg_a, A.dbg_a, 16 * sizeof(double)); }
+    if (A.dbg_n) { if (m->t_dn.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "block scratch"); B.dbg_n = (int*)m->t_dn.p; if (keep_in) in(B.dbg_n, A.dbg_n, sizeof(int)); }
     if (e != hipSuccess) return fail(UMPA_HIP_E_DEVICE, "block gather: %s", hipGetErrorString(e));
-    if (int rc = tiled ? run_tiled(m, B, g, flags, s, 0, nullptr) : run_direct(m, B, s, flags)) return rc;
+    if (int rc = tiled ? run_tiled(m, B, g, flags, s, 0, nullptr, sub) : run_direct(m, B, s, flags)) return rc;
     if (planar) for (int k = 0; k < np; k++) out(A.values + (size_t)k * nfull, B.values + (size_t)k * n, sizeof(double));
     else out(A.values, B.values, np * sizeof(double));
     out(A.err, B.err, sizeof(int));
@@ -500,6 +521,79 @@ int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0,
     return 0;
 }
 
+// Sample stepping without masks: a frame contributes at a pixel iff the pixel lies `padding` inside it (Model.cpp:428-433,
+// :716-719), so the region falls into a grid of rectangles inside each of which the SAME frames contribute -- a plain
+// all-frames problem on that subset (the cost is still divided by the model's frame count, ModelDev::Nwt).  Every rectangle
+// large enough goes down the tiled path with its subset's descriptor list; the general kernels keep the slivers: the last
+// contributing column of a frame (corr_volume would read the frame's very last column as the first half of a 16-byte pair),
+// rectangles below UMPA_STEP_CELL_MIN pixels and rectangles no frame contributes to.
+#define UMPA_STEP_CELL_MIN 1024
+#define UMPA_SUB_SLOTS 256
+int run_stepping_cells(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int flags, hipStream_t s)
+{
+    const int K = m->Na, pad = m->padding;
+    auto lo = [](int vmin, int org, int step, int N) { int q = vmin - org; q = q <= 0 ? 0 : (q + step - 1) / step; return std::min(q, N); };
+    auto hi = [](int vmax, int org, int step, int N) { int q = vmax - org; q = q < 0 ? 0 : q / step + 1; return std::min(q, N); };
+    // per frame, in region pixel indices: rows [ra, rb) and columns [ca, cb) it contributes to; [ca, cs) = without the last column
+    std::vector<int> ra(K), rb(K), ca(K), cb(K), cs(K), rcut{0, A.N0}, ccut{0, A.N1};
+    for (int k = 0; k < K; k++) {
+        const int pi = m->pos[2 * k], pj = m->pos[2 * k + 1], H = m->dims[2 * k], W = m->dims[2 * k + 1];
+        ra[k] = lo(pi + pad, A.org0, A.step0, A.N0); rb[k] = std::max(ra[k], hi(pi + H - pad, A.org0, A.step0, A.N0));
+        ca[k] = lo(pj + pad, A.org1, A.step1, A.N1); cb[k] = std::max(ca[k], hi(pj + W - pad, A.org1, A.step1, A.N1));
+        cs[k] = pair_slack(m) ? cb[k] : std::max(ca[k], std::min(cb[k], hi(pj + W - pad - 1, A.org1, A.step1, A.N1)));
+        rcut.push_back(ra[k]); rcut.push_back(rb[k]);
+        ccut.push_back(ca[k]); ccut.push_back(cb[k]); ccut.push_back(cs[k]);
+    }
+    auto uniq = [](std::vector<int>& v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
+    uniq(rcut); uniq(ccut);
+    if (!m->d_sub) HIP_TRY(hipMalloc((void**)&m->d_sub, (size_t)UMPA_SUB_SLOTS * K * sizeof(FrameDesc)), UMPA_HIP_E_NOMEM);
+    for (size_t x = 0; x + 1 < ccut.size(); x++) {
+        const int c0 = ccut[x], c1 = ccut[x + 1];
+        bool sliver = false;                                          // some frame's last contributing column(s)
+        for (int k = 0; k < K; k++) if (c0 >= cs[k] && c1 <= cb[k] && cs[k] < cb[k]) sliver = true;
+        if (sliver) {                                                 // full height, general kernels (they sort out the frames per pixel)
+            if (int rc = run_block(m, A, g, 0, A.N0, c0, c1, false, flags, s)) return rc;
+            continue;
+        }
+        for (size_t y = 0; y + 1 < rcut.size(); y++) {
+            const int r0 = rcut[y], r1 = rcut[y + 1];
+            std::vector<int> S;
+            for (int k = 0; k < K; k++) if (r0 >= ra[k] && r1 <= rb[k] && c0 >= ca[k] && c1 <= cs[k]) S.push_back(k);
+            unsigned mask = 0;
+            for (int k : S) mask |= 1u << k;
+            const bool known = m->sub_lists.count(mask) != 0;
+            const bool tile = !S.empty() && (size_t)(r1 - r0) * (c1 - c0) >= UMPA_STEP_CELL_MIN &&
+                              ((int)S.size() == K || known || (int)m->sub_lists.size() < UMPA_SUB_SLOTS);
+            if (!tile) { if (int rc = run_block(m, A, g, r0, r1, c0, c1, false, flags, s)) return rc; continue; }
+            if ((int)S.size() == K) { if (int rc = run_block(m, A, g, r0, r1, c0, c1, true, flags, s)) return rc; continue; }   // every frame
+            // this subset's descriptor list (a device slot per subset, uploaded when the frames' addresses have changed --
+            // from pageable memory: the copy has left the host buffer when the call returns) and its box
+            std::vector<FrameDesc> h(S.size());
+            FrameSubset sub;
+            sub.n = (int)S.size();
+            int br0 = 0, br1 = 1 << 30, bc0 = 0, bc1 = 1 << 30;
+            for (int q = 0; q < sub.n; q++) {
+                const int k = S[q];
+                memset(&h[q], 0, sizeof(FrameDesc));
+                h[q].sam = m->d_sam[k]; h[q].ref = m->d_ref[k]; h[q].mask = m->d_mask[k];
+                h[q].H = m->dims[2 * k]; h[q].W = m->dims[2 * k + 1]; h[q].pi = m->pos[2 * k]; h[q].pj = m->pos[2 * k + 1];
+                br0 = std::max(br0, h[q].pi); br1 = std::min(br1, h[q].pi + h[q].H - 1);
+                bc0 = std::max(bc0, h[q].pj); bc1 = std::min(bc1, h[q].pj + h[q].W - 1);
+            }
+            sub.box.r0 = br0; sub.box.r1 = br1; sub.box.c0 = bc0; sub.box.c1 = bc1; sub.box.Wf = m->dims[1]; sub.box.slack = g.box.slack;
+            umpa_hip_model::SubList& L = m->sub_lists[mask];
+            if (!known) L.slot = (int)m->sub_lists.size() - 1;
+            sub.frames = m->d_sub + (size_t)L.slot * K;
+            if (L.host.size() != h.size() || memcmp(L.host.data(), h.data(), h.size() * sizeof(FrameDesc)) != 0) {
+                HIP_TRY(hipMemcpyAsync((void*)sub.frames, h.data(), h.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
+                L.host = h;
+            }
+            if (int rc = run_block(m, A, g, r0, r1, c0, c1, true, flags, s, &sub)) return rc;
+        }
+    }
+    return 0;
+}
+
 int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
               int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
 {
@@ -508,7 +602,9 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
     const bool whole = can_tile && (!g.any_pos || (g.a0 == 0 && g.b0 == A.N0 && g.a1 == 0 && g.b1 == A.N1));
     // sample stepping: the tiled path takes the rectangle every frame contributes to, the general kernels the border
     // strips around it -- worth the split while the rectangle is most of the region
-    const bool split = can_tile && !whole && (size_t)(g.b0 - g.a0) * (g.b1 - g.a1) * 2 >= (size_t)A.N0 * A.N1;
+    // (without masks every rectangle with a constant set of contributing frames can go there, run_stepping_cells)
+    const bool cells = can_tile && !whole && !m->has_mask && m->Na <= 32;
+    const bool split = cells || (can_tile && !whole && (size_t)(g.b0 - g.a0) * (g.b1 - g.a1) * 2 >= (size_t)A.N0 * A.N1);
     if ((flags & UMPA_HIP_F_FORCE_TILED) && !(whole || split))
         return fail(UMPA_HIP_E_UNSUPPORTED, "tiled path does not cover this model/region");
     if (whole && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
@@ -517,11 +613,15 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
         return 0;
     }
     if (split && !(flags & UMPA_HIP_F_FORCE_DIRECT)) {
-        if (int rc = run_block(m, A, g, g.a0, g.b0, g.a1, g.b1, true, flags, s)) return rc;           // centre: tiled
-        if (int rc = run_block(m, A, g, 0, g.a0, 0, A.N1, false, flags, s)) return rc;                 // top strip
-        if (int rc = run_block(m, A, g, g.b0, A.N0, 0, A.N1, false, flags, s)) return rc;              // bottom strip
-        if (int rc = run_block(m, A, g, g.a0, g.b0, 0, g.a1, false, flags, s)) return rc;              // left strip
-        if (int rc = run_block(m, A, g, g.a0, g.b0, g.b1, A.N1, false, flags, s)) return rc;           // right strip
+        if (cells) {
+            if (int rc = run_stepping_cells(m, A, g, flags, s)) return rc;
+        } else {
+            if (int rc = run_block(m, A, g, g.a0, g.b0, g.a1, g.b1, true, flags, s)) return rc;           // centre: tiled
+            if (int rc = run_block(m, A, g, 0, g.a0, 0, A.N1, false, flags, s)) return rc;                 // top strip
+            if (int rc = run_block(m, A, g, g.b0, A.N0, 0, A.N1, false, flags, s)) return rc;              // bottom strip
+            if (int rc = run_block(m, A, g, g.a0, g.b0, 0, g.a1, false, flags, s)) return rc;              // left strip
+            if (int rc = run_block(m, A, g, g.a0, g.b0, g.b1, A.N1, false, flags, s)) return rc;           // right strip
+        }
         if (on_rows) on_rows(0, A.N0);
         m->last_path = 4;
         return 0;
@@ -623,7 +723,7 @@ umpa_hip_model* umpa_hip_create(int kind, int Na, const int* dims, double* const
         size_t total = 0;
         for (int k = 0; k < Na; k++) total += (size_t)dims[2 * k] * dims[2 * k + 1];
         const size_t nstacks = m->has_mask ? 3 : 2;
-        ok = hipMalloc(&m->d_frames_blob, total * nstacks * sizeof(double)) == hipSuccess;
+        ok = hipMalloc(&m->d_frames_blob, total * nstacks * sizeof(double) + 16) == hipSuccess;     // (+16: pair_slack below)
         if (!ok) fail(UMPA_HIP_E_NOMEM, "cannot allocate %zu bytes for the frame stacks", total * nstacks * sizeof(double));
         double* base = (double*)m->d_frames_blob;
         size_t off = 0;
@@ -703,7 +803,7 @@ int umpa_hip_stage_sample(umpa_hip_model* m, const void* const* raw, int raw_dty
     if (!m->up_stream) HIP_TRY(hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking), UMPA_HIP_E_DEVICE);
     if (!m->ev_staged) HIP_TRY(hipEventCreateWithFlags(&m->ev_staged, hipEventDisableTiming), UMPA_HIP_E_DEVICE);
     if (!m->d_back_blob) {
-        HIP_TRY(hipMalloc(&m->d_back_blob, total * sizeof(double)), UMPA_HIP_E_NOMEM);
+        HIP_TRY(hipMalloc(&m->d_back_blob, total * sizeof(double) + 16), UMPA_HIP_E_NOMEM);
         m->d_sam_back.resize(m->Na);
         size_t off = 0;
         for (int k = 0; k < m->Na; k++) { m->d_sam_back[k] = (double*)m->d_back_blob + off; off += (size_t)m->dims[2 * k] * m->dims[2 * k + 1]; }
@@ -801,6 +901,7 @@ void umpa_hip_destroy(umpa_hip_model* m)
     m->b_covout.release(); m->b_small.release(); m->b_kern.release();
     m->t_values.release(); m->t_uv.release(); m->t_err.release(); m->t_cover.release(); m->t_dd.release(); m->t_da.release(); m->t_dn.release();
     if (m->d_desc) (void)hipFree(m->d_desc);
+    if (m->d_sub) (void)hipFree(m->d_sub);
     if (m->d_win) (void)hipFree(m->d_win);
     if (m->d_frames_blob) (void)hipFree(m->d_frames_blob);
     if (m->d_back_blob) (void)hipFree(m->d_back_blob);

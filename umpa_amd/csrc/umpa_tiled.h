@@ -250,7 +250,7 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
     // window positions (Model.cpp:688-701)
     const size_t xs = ref_mode ? (size_t)(i - si) * M.W + (j - sj) : (size_t)i * M.W + j;
     const size_t xr = ref_mode ? (size_t)i * M.W + j : (size_t)(i + si) * M.W + (j + sj);
-    const double rwt = 1.0 / (double)m.Na;                          // wave-uniform: scalar
+    const double rwt = 1.0 / (double)m.Nwt;                         // wave-uniform: scalar
     double t1 = pc.t1, t3 = pc.t3;
     if (ref_mode) t1 = NA > 0 ? ld_off(gp(M.SamSq), (unsigned)xs * 8u) : gp(M.SamSq)[xs];
     else t3 = NA > 0 ? ld_off(gp(M.RefSq), (unsigned)xr * 8u) : gp(M.RefSq)[xr];
@@ -340,7 +340,7 @@ __device__ __forceinline__ void lookup_solve(const ModelDev& m, int ref_mode, co
                                              const double* fixed, const PixConst& pc, double& cost, Fit& fit)
 {
     const double t5 = raw.t5;
-    const double rwt = 1.0 / (double)m.Na;
+    const double rwt = 1.0 / (double)m.Nwt;
     double t1 = pc.t1, t3 = pc.t3;
     if (ref_mode) t1 = raw.sq; else t3 = raw.sq;
     if (KIND == 1) {
@@ -865,7 +865,7 @@ inline size_t tiled_table_budget()
 // `piece_rows` > 0: row chunks of at most that many dense rows (a multiple of 32) even where the table budget would
 // allow more (the host-array entry point downloads the rows of chunk c while chunk c+1 is being matched, the multi-GPU
 // leg sends them to rank 0); `on_rows(xi_lo, xi_hi)` is called after the kernels of a chunk have been enqueued.
-struct FrameBox { int r0, r1, c0, c1, Wf; };
+struct FrameBox { int r0, r1, c0, c1, Wf; int slack; };   // slack: 1 if 8 readable bytes follow every frame row's last column
 
 inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const FrameBox& box, const RegionArgs& A,
                        hipStream_t s, TiledTimers* tt, bool reuse_ref_maps,
@@ -963,7 +963,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         CA.table = st.table; CA.slot_stride = (size_t)drows * N1d;
         CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = drow0; CA.rows = drows; CA.N1 = N1d;
         CA.sigma = dev.ref_mode ? -1 : 1;
-        CA.br0 = box.r0; CA.br1 = box.r1; CA.bc0 = box.c0; CA.bc1 = box.c1; CA.Wf = box.Wf;
+        CA.br0 = box.r0; CA.br1 = box.r1; CA.bc0 = box.c0; CA.bc1 = box.c1 + box.slack; CA.Wf = box.Wf;   // (pairs may start on column c1 then)
         { const char* ab = getenv("UMPA_HIP_ABLATE"); CA.ablate = ab ? atoi(ab) : 0; }
         CA.ntx = CA.nty = 0;                                          // set by launch_corr for the tile shape it picks
         // output rows whose dense row lies in [drow0, drow0 + drows)
