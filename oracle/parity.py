@@ -47,7 +47,8 @@ def assert_parity(got, want, max_shift, label="", allow_illposed=None, subpx=-1,
       (iv)  err == 0 pixels: dx, dy bit-exact; T, df, f <= 1e-5 relative.  `f` is excluded where the walk
             failed before its first move: the reference then returns an uninitialised stack variable
             (`T D;` in Model.cpp:566/:927 is only assigned at Optim.cpp:423 or :399-404); this repo's
-            implementations return 0.0 there."""
+            implementations return 0.0 there.  A failed pixel's `f` that is below 1e-10 of the largest cost in its
+            own 5x5 memo is cancellation noise and is not compared relatively."""
     assert got["err"].shape == want["err"].shape, label
     assert got["err"].dtype == np.int32
     np.testing.assert_array_equal(got["err"], want["err"], err_msg=label + " err")
@@ -105,6 +106,12 @@ def assert_parity(got, want, max_shift, label="", allow_illposed=None, subpx=-1,
             np.testing.assert_array_equal(got[k][bad], want[k][bad], err_msg=label + " " + k + " on failed pixels")
         sel = bad & ~n1 & np.isfinite(want["f"]) & (got["f"] != 0.0) & bool(f_on_failed)
         r = rel(got["f"], want["f"])
+        if "debug_d" in want:
+            # a cost that cancels to (almost) nothing -- t1 - t5^2/t3 on a window the model fits exactly -- is rounding noise
+            # of its terms: no relative bar applies below 1e-10 of the largest cost the same walk has seen (its 5x5 memo;
+            # seen with 3x3 windows, one frame, masks: 5.9e-17 against 1.5e-16 beside neighbours of 5.5e-4)
+            scale = np.max(np.abs(np.where(want["debug_d"] < 0, 0.0, want["debug_d"])).reshape(want["err"].shape + (-1,)), axis=-1)
+            sel = sel & ~(np.abs(got["f"] - want["f"]) <= 1e-10 * scale)
         assert not np.any(r[sel] > RTOL), "%s f: max rel %.3e on failed pixels" % (label, r[sel].max())
     OBSERVED.append((label, int(ok.sum()), int(inside.sum()), int(unconverged)))
     return dict(ok=int(ok.sum()), inside=int(inside.sum()), unconverged=int(unconverged))

@@ -40,8 +40,20 @@ def _configs(n, seed):
                  dxdy=None if rng.random() < 0.7 else (int(rng.integers(-1, 2)), int(rng.integers(-1, 2))),
                  mask=bool(rng.random() < 0.2), force=int(rng.choice([0, 0, 0, 2])),      # 2 = UMPA_HIP_F_FORCE_DIRECT
                  amp=float(rng.uniform(0.2, max(0.3, ms - 1.2))), seed=1000 + q)
+        # (after the draw, so that the committed sweep keeps its other cases) one frame, 3x3 windows and masks: windows with
+        # two or three valid pixels are fitted EXACTLY, every cost is rounding noise around zero and the walk follows the
+        # noise (seen in a soak run: the oracle bounces until the call cap, the table-based path stops after 33 calls)
+        if c["mask"] and c["K"] == 1 and c["Nw"] == 1:
+            c["K"] = 2
         out.append(c)
     return out
+
+
+# Windows of 3x3 or 5x5 pixels on few frames give flat cost valleys: 0.4-0.7 % of the ok pixels end on a Newton iteration
+# the reference itself has not converged (soak runs, seeds 777001 and 20261003 at scale 3); every one of them is still
+# classified pixel by pixel (oracle/parity.py), only the count cap for cases without a recorded count is wider there.
+def _illposed_share(c):
+    return 0.012 if c["Nw"] <= 2 else None
 
 
 # UMPA_FUZZ_N / UMPA_FUZZ_SEED: a longer or different sweep for soak runs (the committed default is what the suite runs)
@@ -70,7 +82,7 @@ def test_random_configuration(namespaces, c):
     if c["dxdy"] is not None:
         kw["dxdy"] = c["dxdy"]
     got, want = g.match(**kw), o.match(**kw)
-    assert_parity(got, want, c["ms"], str(c), subpx=c["subpx"])
+    assert_parity(got, want, c["ms"], str(c), subpx=c["subpx"], allow_illposed=_illposed_share(c))
 
 
 def _stepping_configs(n, seed):
@@ -109,5 +121,5 @@ def test_random_sample_stepping(namespaces, c):
     g, o = getattr(hip_ns, name)(sam, ref, **kw), getattr(port_ns, name)(sam, ref, **kw)
     g.assign_coordinates = o.assign_coordinates = c["assign"]
     got, want = g.match(step=c["step"], quiet=True), o.match(step=c["step"], quiet=True)
-    assert_parity(got, want, c["ms"], "stepping " + str(c))
+    assert_parity(got, want, c["ms"], "stepping " + str(c), allow_illposed=_illposed_share(c))
     np.testing.assert_array_equal(g.coverage(), o.coverage())
