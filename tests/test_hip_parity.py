@@ -327,8 +327,9 @@ def test_sample_stepping_on_the_tiled_path(hip_ns, port_ns, variant):
     np.testing.assert_array_equal(g.coverage(), o.coverage())
 
 
-@pytest.mark.parametrize("df,assign", [(True, "sam"), (False, "ref"), (True, "ref")])
-def test_sample_stepping_border_rectangles_on_the_tiled_path(hip_ns, port_ns, df, assign):
+@pytest.mark.parametrize("df,assign,masked", [(True, "sam", False), (False, "ref", False), (True, "ref", False),
+                                              (True, "sam", True), (False, "ref", True)])
+def test_sample_stepping_border_rectangles_on_the_tiled_path(hip_ns, port_ns, df, assign, masked):
     """A 2 x 2 grid of positions: the region falls into rectangles with a constant set of contributing frames.  The large
     ones (the centre with every frame, the four edges with half of them, the corners with a quarter) each run on the tiled
     path with their subset's frames -- the cost still divided by the model's frame count --, the slivers (a frame's last
@@ -341,6 +342,9 @@ def test_sample_stepping_border_rectangles_on_the_tiled_path(hip_ns, port_ns, df
     sam = [np.ascontiguousarray(f[0][0]) for f in frames]
     ref = [np.ascontiguousarray(f[1][0]) for f in frames]
     kw = dict(window_size=Nw, max_shift=ms, pos_list=pos)
+    if masked:                                                      # the masked table kernel takes the same rectangles
+        rng = np.random.default_rng(21)
+        kw["mask_list"] = [(rng.random(a.shape) < 0.93).astype(np.float64) for a in sam]
     name = "UMPAModelDF" if df else "UMPAModelNoDF"
     g, o = getattr(hip_ns, name)(sam, ref, **kw), getattr(port_ns, name)(sam, ref, **kw)
     g.assign_coordinates = o.assign_coordinates = assign
@@ -354,13 +358,15 @@ def test_sample_stepping_border_rectangles_on_the_tiled_path(hip_ns, port_ns, df
         lib.timing_read(h, q, ctypes.byref(nm), ctypes.byref(tot), ctypes.byref(cnt))
         launches[nm.value.decode()] = cnt.value
     lib.timing_enable(h, 0)
-    assert launches.get("corr_volume", 0) >= 9, launches           # centre + 4 edges + 4 corners
-    st = assert_parity(got, want, ms, "stepping rectangles %s %s" % (name, assign))
+    assert launches.get("corr_masked" if masked else "corr_volume", 0) >= 9, launches      # centre + 4 edges + 4 corners
+    st = assert_parity(got, want, ms, "stepping rectangles %s %s%s" % (name, assign, " masked" if masked else ""))
     assert st["ok"] > 100000
     # the same through a ROI with steps and a start shift (the rectangles move with the region's origin and step)
     mk = dict(quiet=True, ROI=((3, 400, 2), (5, 480, 1)), dxdy=(1, -1))
     got, want = g.match(**mk), o.match(**mk)
-    assert_parity(got, want, ms, "stepping rectangles ROI %s %s" % (name, assign))
+    assert_parity(got, want, ms, "stepping rectangles ROI %s %s%s" % (name, assign, " masked" if masked else ""))
+    if masked:
+        np.testing.assert_array_equal(g.coverage(), o.coverage())
     # a second match of the same model takes the cached descriptor lists
     got2 = g.match(**mk)
     for k in ("f", "dx", "dy", "T", "err"):

@@ -455,7 +455,7 @@ int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int fla
     if (sub) { dev.frames = sub->frames; dev.Na = sub->n; m->tiled.ref_maps_ok = false; }      // (Nwt stays the model's frame count)
     const bool reuse = !sub && (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0;
     int rc = m->has_mask
-        ? tiled_match_masked(m->tiled, dev, m->kind, g.Himg, g.Wimg, g.box, A, s,
+        ? tiled_match_masked(m->tiled, dev, m->kind, g.Himg, g.Wimg, sub ? sub->box : g.box, A, s,
                              m->timing ? &tt : nullptr, reuse, m->mask_binary, piece_rows, on_rows)
         : tiled_match(m->tiled, dev, m->kind, g.Himg, g.Wimg, sub ? sub->box : g.box, A, s,
                       m->timing ? &tt : nullptr, reuse, piece_rows, on_rows);
@@ -521,9 +521,10 @@ int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0,
     return 0;
 }
 
-// Sample stepping without masks: a frame contributes at a pixel iff the pixel lies `padding` inside it (Model.cpp:428-433,
-// :716-719), so the region falls into a grid of rectangles inside each of which the SAME frames contribute -- a plain
-// all-frames problem on that subset (the cost is still divided by the model's frame count, ModelDev::Nwt).  Every rectangle
+// Sample stepping: a frame contributes at a pixel iff the pixel lies `padding` inside it (Model.cpp:428-433, :716-719), so
+// the region falls into a grid of rectangles inside each of which the SAME frames contribute -- a plain all-frames problem
+// on that subset (without masks the cost is still divided by the model's frame count, ModelDev::Nwt; with masks by the sum
+// of the pair weights, which only the contributing frames add to).  Every rectangle
 // large enough goes down the tiled path with its subset's descriptor list; the general kernels keep the slivers: the last
 // contributing column of a frame (corr_volume would read the frame's very last column as the first half of a 16-byte pair),
 // rectangles below UMPA_STEP_CELL_MIN pixels and rectangles no frame contributes to.
@@ -602,8 +603,8 @@ int run_match(umpa_hip_model* m, const RegionArgs& A, int flags, hipStream_t s,
     const bool whole = can_tile && (!g.any_pos || (g.a0 == 0 && g.b0 == A.N0 && g.a1 == 0 && g.b1 == A.N1));
     // sample stepping: the tiled path takes the rectangle every frame contributes to, the general kernels the border
     // strips around it -- worth the split while the rectangle is most of the region
-    // (without masks every rectangle with a constant set of contributing frames can go there, run_stepping_cells)
-    const bool cells = can_tile && !whole && !m->has_mask && m->Na <= 32;
+    // (every rectangle with a constant set of contributing frames can go there, run_stepping_cells)
+    const bool cells = can_tile && !whole && m->Na <= 32;
     const bool split = cells || (can_tile && !whole && (size_t)(g.b0 - g.a0) * (g.b1 - g.a1) * 2 >= (size_t)A.N0 * A.N1);
     if ((flags & UMPA_HIP_F_FORCE_TILED) && !(whole || split))
         return fail(UMPA_HIP_E_UNSUPPORTED, "tiled path does not cover this model/region");
