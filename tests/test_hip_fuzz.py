@@ -52,7 +52,11 @@ def _configs(n, seed):
 # Windows of 3x3 or 5x5 pixels on few frames give flat cost valleys: 0.4-0.7 % of the ok pixels end on a Newton iteration
 # the reference itself has not converged (soak runs, seeds 777001 and 20261003 at scale 3); every one of them is still
 # classified pixel by pixel (oracle/parity.py), only the count cap for cases without a recorded count is wider there.
+# A dark-field fit from one or two frames is flatter still (soak seed 99173: 1.6-1.9 % at 3x3 windows, on the general kernel as
+# on the tiled path).
 def _illposed_share(c):
+    if c["df"] and c["K"] <= 2:
+        return 0.025
     return 0.012 if c["Nw"] <= 2 else None
 
 

@@ -70,7 +70,7 @@ template <int KIND, int NW>
 // three workgroups per CU where the window leaves the registers for it (C2: 0.42 -> 0.375 ms; at Nw = 7 the 168-register
 // cap spills and loses: C3 3.9 -> 4.3 ms)
 __global__ void __launch_bounds__(256, NW <= 5 ? 3 : 2)
-prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
+prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides, int tx0, int ty0)
 {
     // sides: bit 0 = the sample-side maps (SamSq, WS_k), bit 1 = the reference-side maps (RefSq, MR_k).
     // A model whose reference stack has not changed since the last match only recomputes the sample side.
@@ -82,7 +82,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides)
 
     const int lin = xcd_band_remap(blockIdx.x, ntx * nty);
     if (lin >= ntx * nty) return;
-    const int tx = lin % ntx, ty = lin / ntx;
+    const int tx = tx0 + lin % ntx, ty = ty0 + lin / ntx;              // (tx0, ty0): first tile of the rectangle the match needs
     // outputs live on x in [NW, H-NW) x [NW, W-NW); this tile's first output pixel:
     const int r0 = NW + ty * C::T, c0 = NW + tx * C::T;
     const int tid = threadIdx.x;
@@ -514,6 +514,7 @@ struct TiledState {
     bool ref_maps_ok = false;
     int ref_kind = -1, ref_K = 0;
     size_t ref_plane = 0;
+    int ref_rect[4] = {0, 0, 0, 0};   // tiles (tx0, tx1, ty0, ty1) of the maps that were computed (PrepRect)
     // on-demand passes (umpa_ondemand.h): device scratch, and page-locked slots the counters of a timed match land in
     void* od_buf = nullptr;   size_t od_cap = 0;
     int* od_host = nullptr;   int od_slot = 0;
@@ -733,8 +734,25 @@ inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A,
     return launch_corr_shape<NW, 5>(dev, A, sep, s, L);
 }
 
+// The tiles of the maps a region needs: its pixels, seen from the image, and max_shift around them (a map is read at the
+// pixel and at the pixel + shift).  Matches of a part of the image -- a ROI, one rectangle of a sample-stepping stack -- then
+// pay for their part of the maps only.
+struct PrepRect { int tx0, tx1, ty0, ty1; };
+template <int NW>
+inline PrepRect prep_rect(const Maps& M, const RegionArgs& A, int ms)
+{
+    const int T = PrepCfg<NW>::T;
+    const int ntx = (M.W - 2 * NW + T - 1) / T, nty = (M.H - 2 * NW + T - 1) / T;
+    auto lo = [&](int x) { const int q = (x - ms - NW) / T; return x - ms - NW < 0 ? 0 : q; };
+    auto hi = [&](int x, int n) { const int q = (x + ms - NW) / T + 1; return q > n ? n : (q < 0 ? 0 : q); };
+    PrepRect R;
+    R.ty0 = std::min(lo(A.org0), nty); R.ty1 = std::max(R.ty0, hi(A.org0 + A.step0 * (A.N0 - 1), nty));
+    R.tx0 = std::min(lo(A.org1), ntx); R.tx1 = std::max(R.tx0, hi(A.org1 + A.step1 * (A.N1 - 1), ntx));
+    return R;
+}
+
 template <int KIND, int NW>
-inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& sep, int sides, hipStream_t s)
+inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& sep, int sides, hipStream_t s, const PrepRect& PR)
 {
     using C = PrepCfg<NW>;
     static bool attr_set[64] = {};                                    // the attribute is per device
@@ -749,9 +767,9 @@ inline hipError_t launch_prep(const ModelDev& dev, const Maps& M, const Sep1D& s
             attr_set[devid & 63] = true;
         }
     }
-    const int ntx = (M.W - 2 * NW + C::T - 1) / C::T, nty = (M.H - 2 * NW + C::T - 1) / C::T;
+    const int ntx = PR.tx1 - PR.tx0, nty = PR.ty1 - PR.ty0;
     const int total = ntx * nty, grid = ((total + 7) / 8) * 8;
-    hipLaunchKernelGGL((prep_maps_kernel<KIND, NW>), dim3(grid), dim3(C::NT), C::LDS, s, dev, M, sep, ntx, nty, sides);
+    if (total > 0) hipLaunchKernelGGL((prep_maps_kernel<KIND, NW>), dim3(grid), dim3(C::NT), C::LDS, s, dev, M, sep, ntx, nty, sides, PR.tx0, PR.ty0);
     return hipGetLastError();
 }
 
@@ -946,13 +964,17 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
 
     hipError_t e = hipErrorInvalidValue;
     tic(2);
-    const int sides = (reuse_ref_maps && st.ref_maps_ok) ? 1 : 3;
+    PrepRect PRc = {0, 0, 0, 0};
+    UMPA_NW_SWITCH(Nw, (PRc = prep_rect<NWC>(M, A, ms)))
+    const bool covered = st.ref_rect[0] <= PRc.tx0 && st.ref_rect[1] >= PRc.tx1 && st.ref_rect[2] <= PRc.ty0 && st.ref_rect[3] >= PRc.ty1;
+    const int sides = (reuse_ref_maps && st.ref_maps_ok && covered) ? 1 : 3;
     st.ref_maps_ok = false;
-    if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, sides, s))) }
-    else { UMPA_NW_SWITCH(Nw, (e = launch_prep<0, NWC>(dev, M, st.sep, sides, s))) }
+    if (kind == 1) { UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, sides, s, PRc))) }
+    else { UMPA_NW_SWITCH(Nw, (e = launch_prep<0, NWC>(dev, M, st.sep, sides, s, PRc))) }
     toc();
     if (e != hipSuccess) return (int)e;
     st.ref_maps_ok = true; st.ref_kind = kind; st.ref_K = K; st.ref_plane = plane;
+    st.ref_rect[0] = PRc.tx0; st.ref_rect[1] = PRc.tx1; st.ref_rect[2] = PRc.ty0; st.ref_rect[3] = PRc.ty1;
 
     int ub = pick_ub(UJ);
     { const char* e = getenv("UMPA_HIP_UB"); if (e) ub = atoi(e); }      // tuning override: 9, 8, 7 or 5
@@ -1198,13 +1220,17 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
 
     hipError_t e = hipErrorInvalidValue;
     if (kind == 1) {
-        const int sides = (reuse_ref_maps && st.ref_maps_ok) ? 0 : 3;   // only the reference means are read: nothing to redo for a new sample stack
+        PrepRect PRc = {0, 0, 0, 0};
+        UMPA_NW_SWITCH(Nw, (PRc = prep_rect<NWC>(M, A, ms)))
+        const bool covered = st.ref_rect[0] <= PRc.tx0 && st.ref_rect[1] >= PRc.tx1 && st.ref_rect[2] <= PRc.ty0 && st.ref_rect[3] >= PRc.ty1;
+        const int sides = (reuse_ref_maps && st.ref_maps_ok && covered) ? 0 : 3;   // only the reference means are read: nothing to redo for a new sample stack
         st.ref_maps_ok = false;
         if (sides) {
             tic(2);
-            UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, sides, s)))
+            UMPA_NW_SWITCH(Nw, (e = launch_prep<1, NWC>(dev, M, st.sep, sides, s, PRc)))
             toc();
             if (e != hipSuccess) return (int)e;
+            st.ref_rect[0] = PRc.tx0; st.ref_rect[1] = PRc.tx1; st.ref_rect[2] = PRc.ty0; st.ref_rect[3] = PRc.ty1;
         }
         st.ref_maps_ok = true; st.ref_kind = kind; st.ref_K = K; st.ref_plane = plane;
     }
