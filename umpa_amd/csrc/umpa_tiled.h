@@ -701,7 +701,9 @@ template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     const int want = tiled_corr_shape();
-    const bool ro3_pays = (2 * dev.ms - 1) % 3 == 0;                  // three row offsets per pass: no idle third pass
+    // three row offsets per pass: no idle third pass; and enough frames for the staging it saves to outweigh its longer flush
+    // (5 frames, C5: 3.87 against 3.80 ms per projection with the two-per-CU shape)
+    const bool ro3_pays = (2 * dev.ms - 1) % 3 == 0 && dev.Na >= 7;
     // (two row offsets per pass, 384 threads with 6 columns each -- the window of C3 does not fit the 512 x 4-column shape:
     //  C3 35.8 -> 34.3 ms; not kept, 4 % do not pay for another set of instantiations)
     const bool ro2_pays = false;
