@@ -433,13 +433,14 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
             // plane wave-uniform -- the table slot's base address is a scalar, the lane's offset inside a slot is the same in
             // every round.  Column pairs swap half of their rows as below.  Tiles that reach over the region's edge, and odd
             // N1, take the general code.
-            static_assert(PR * (C::TR / C::CB) * TC <= NT && (TC * (C::TR / C::CB)) % 64 == 0 && TC == 32, "one item per thread, plane per wave");
+            // (a plane takes 32 lanes per row block, also on narrower tiles, where the lanes past the last column idle)
+            static_assert(PR * (C::TR / C::CB) * 32 <= NT && TC <= 32 && TC % 2 == 0, "one item per thread, plane per two waves");
             const bool inside = prow0 + C::TR <= A.row0 + A.rows && pcol0 + TC <= A.N1 && vec_ok && !(A.ablate & 16);
             if (inside) {
-                const int pl = __builtin_amdgcn_readfirstlane(tid / (TC * (C::TR / C::CB)));
+                const int pl = __builtin_amdgcn_readfirstlane(tid / (32 * (C::TR / C::CB)));
                 const int P = f * PR + pl, g = P / UB, u = P - g * UB;
-                if (pl < PR && P < C::NPL && u < nu && oi0 + g <= ms - 1) {
-                    const int c = tid % TC, rb = (tid / TC) % (C::TR / C::CB), odd = c & 1;
+                const int c = tid % 32, rb = (tid / 32) % (C::TR / C::CB), odd = c & 1;
+                if (pl < PR && P < C::NPL && u < nu && oi0 + g <= ms - 1 && c < TC) {
                     double out[C::CB];
                     fir_running<NW, C::CB>(reinterpret_cast<const double*>(__builtin_assume_aligned(hout + pl * C::HPL + c * C::HQP + rb * C::CB, 16)),
                                            1, sep.hr, out);
