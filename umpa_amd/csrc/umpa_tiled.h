@@ -695,16 +695,19 @@ inline hipError_t launch_corr(const ModelDev& dev, CorrArgs A, const Sep1D& sep,
 // Shape 5 (round 3): 32x32 tiles / 512 threads / ONE per CU, every product thread accumulates THREE row offsets from one
 // staging (RO = 3, 4 columns x UB offsets x 3 = up to 108 accumulators of the 128 a thread can hold), flush in rounds of three
 // planes (as many rounds as column offsets).  A third of the L2 -> LDS traffic per plane: C2 1.64-1.72 -> 1.31-1.45 (same
-// boxes).  Taken when 2 max_shift - 1 is a multiple of three (no idle third pass) and the window is at most 13 wide.
+// boxes).  Taken for stacks of at least 7 frames and windows up to 13 wide.
 // Shape 6: the same on 24-column tiles for wider windows (C3: 34.4 -> 28.9 ms).
 #define UMPA_CORR_SHAPES(X) X(5, 32, 512, 1, 1, 9, 3) X(6, 24, 512, 1, 1, 9, 3) X(1, 32, 256, 1, 2, 2, 1) X(2, 24, 256, 1, 2, 2, 1) X(3, 16, 256, 1, 2, 1, 1) X(4, 32, 512, 1, 1, 2, 1)
 template <int NW, int UB>
 inline hipError_t launch_corr_shape(const ModelDev& dev, const CorrArgs& A, const Sep1D& sep, hipStream_t s, CorrLaunch& L)
 {
     const int want = tiled_corr_shape();
-    // three row offsets per pass: no idle third pass; and enough frames for the staging it saves to outweigh its longer flush
-    // (5 frames, C5: 3.87 against 3.80 ms per projection with the two-per-CU shape)
-    const bool ro3_pays = (2 * dev.ms - 1) % 3 == 0 && dev.Na >= 7;
+    // three row offsets per pass: enough frames for the staging it saves to outweigh its longer flush (5 frames, C5: 3.87
+    // against 3.80 ms per projection with the two-per-CU shape).  An idle third of the last pass (2 max_shift - 1 not a
+    // multiple of three) costs less than it saves (tools/shape_rate.py, C2's stack, shape 1 -> 5: max_shift 3: 0.69 -> 0.60 ms,
+    // 4: 1.22 -> 1.10, 6: 3.27 -> 2.76, 7: 3.87 -> 3.33; window 7, max_shift 4: 1.12 -> 1.10; window 15, max_shift 6,
+    // shape 2 -> 6: 4.43 -> 4.10)
+    const bool ro3_pays = dev.Na >= 7;
     // (two row offsets per pass, 384 threads with 6 columns each -- the window of C3 does not fit the 512 x 4-column shape:
     //  C3 35.8 -> 34.3 ms; not kept, 4 % do not pay for another set of instantiations)
     const bool ro2_pays = false;
