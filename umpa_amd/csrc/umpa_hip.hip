@@ -379,6 +379,13 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A, bool forced 
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
     // corr_volume / corr_masked address a frame with 32-bit byte offsets (LDS-DMA source = base + per-lane offset)
     if ((size_t)m->dims[0] * m->dims[1] * sizeof(double) >= ((size_t)1 << 32)) return false;
+    if (m->has_mask && m->kind == UMPA_HIP_KIND_DF) {                 // corr_masked stages the means from 16-byte pair planes of the IMAGE
+        size_t Himg = 0, Wimg = 0;
+        for (int k = 0; k < m->Na; k++) {
+            Himg = std::max(Himg, (size_t)m->pos[2 * k] + m->dims[2 * k]); Wimg = std::max(Wimg, (size_t)m->pos[2 * k + 1] + m->dims[2 * k + 1]);
+        }
+        if (Himg * Wimg * 16 >= ((size_t)1 << 32)) return false;
+    }
     // stepped regions: the tiled kernels still compute the dense grid, the direct kernel only the requested pixels at
     // about 20 costs each.  Measured on 2048^2 x 10 frames, Nw 5, max_shift 5 (tools/step_rate.py): step 3: 3.5 vs 9.8 ms,
     // 4: 2.5 vs 7.6, 5: 2.4 vs 6.8, 6: 2.4 vs 5.0 -- the dense grid wins up to about 64 dense pixels per requested

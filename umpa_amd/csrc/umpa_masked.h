@@ -57,8 +57,11 @@ struct MaskCfg {
     static constexpr int BW = (QC + UB) & ~1;
     static constexpr int PA = (QC / 2) | 1, PB = (BW / 2) | 1;                  // 16-byte pieces per image row: odd
     // one staged frame: images A, mask under A, B, mask under B, in piece order
-    static constexpr int OFF_MA = QR * PA, OFF_B = 2 * QR * PA, OFF_MB = 2 * QR * PA + QR * PB;
-    static constexpr int NPIECE = 2 * QR * PA + 2 * QR * PB;
+    // (each image starts at a multiple of 64 pieces: a wave-instruction of the LDS-DMA reads one array only and its base is a
+    // scalar, as in corr_volume)
+    static constexpr int IMG_A = (QR * PA + 63) & ~63, IMG_B = (QR * PB + 63) & ~63;
+    static constexpr int OFF_MA = IMG_A, OFF_B = 2 * IMG_A, OFF_MB = 2 * IMG_A + IMG_B;
+    static constexpr int NPIECE = 2 * IMG_A + IMG_B + QR * PB;
     static constexpr int NPT = (NPIECE + NT - 1) / NT;
     static constexpr int OVER = 2 * (NQB * (QB / 2) - (QB / 2) + NBP) - 2 * PB;  // the last block's reads past its image row
     static constexpr int SLOT_IMG = NPIECE * 2 + (OVER > 0 ? OVER : 0);
@@ -150,21 +153,26 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
 
     // ---- LDS-DMA pieces of this thread (see corr_volume): 16 bytes = two adjacent columns of one frame row
     unsigned src_off[C::NPT];
-    unsigned src_sel = 0;                                               // 2 bits per piece: 0 A, 1 mask under A, 2 B, 3 mask under B
 #pragma unroll
     for (int n = 0; n < C::NPT; n++) {
         const int p = tid + n * NT;
         int img, q;
-        if (p < C::OFF_MA) { img = 0; q = p; }
-        else if (p < C::OFF_B) { img = 1; q = p - C::OFF_MA; }
-        else if (p < C::OFF_MB) { img = 2; q = p - C::OFF_B; }
+        if (p < C::OFF_MA) { img = 0; q = min(p, C::QR * C::PA - 1); }
+        else if (p < C::OFF_B) { img = 1; q = min(p - C::OFF_MA, C::QR * C::PA - 1); }
+        else if (p < C::OFF_MB) { img = 2; q = min(p - C::OFF_B, C::QR * C::PB - 1); }
         else { img = 3; q = min(p - C::OFF_MB, C::QR * C::PB - 1); }
         int r, c;
         if (img < 2) { r = q / C::PA; c = 2 * (q % C::PA); }
         else { r = q / C::PB + oi0; c = 2 * (q % C::PB) + oj0; }
         const int gr = min(max(fr0 + r, A.br0), A.br1), gc = min(max(fc0 + c, A.bc0), A.bc1 - 1);
         src_off[n] = (unsigned)(gr * A.Wf + gc) * 8u;
-        src_sel |= (unsigned)img << (2 * n);
+    }
+    const unsigned wave_piece0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);
+    unsigned src_sel = 0;                                               // 2 bits per instruction of this wave: 0 A, 1 mask under A, 2 B, 3 mask under B
+#pragma unroll
+    for (int n = 0; n < C::NPT; n++) {
+        const unsigned p0 = wave_piece0 + n * NT;
+        src_sel |= (p0 < (unsigned)C::OFF_MA ? 0u : p0 < (unsigned)C::OFF_B ? 1u : p0 < (unsigned)C::OFF_MB ? 2u : 3u) << (2 * n);
     }
     // DF: pieces of the means of a frame pair: piece p = pixel (p / MW, p % MW) of the tile rows x (tile columns widened by the
     // column offsets); the reference window sits at p + u in 'sam' mode, at p in 'ref' mode (Model.cpp:688-701)
@@ -181,7 +189,6 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
         }
     }
     const size_t mplane = (size_t)A.H * A.W;
-    const unsigned wave_piece0 = (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63);
     auto issue_frame = [&](int k) {
         const FrameDesc fd = load_frame(m.frames, k);
         const long shift = ((long)fd.pi * A.Wf + fd.pj) * 8;
@@ -191,9 +198,8 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
         UMPA_LDS_AS char* slot = (UMPA_LDS_AS char*)(ring + (k % C::NSLOT) * C::SLOT);
 #pragma unroll
         for (int n = 0; n < C::NPT; n++) {
-            const unsigned sel = (src_sel >> (2 * n)) & 3u;
-            const UMPA_GLOBAL char* src = (sel == 0 ? gA : sel == 2 ? gB : gM) + src_off[n];
-            __builtin_amdgcn_global_load_lds(src, slot + (size_t)(wave_piece0 + n * NT) * 16, 16, 0, 0);
+            const unsigned sel = (src_sel >> (2 * n)) & 3u;                                     // (wave-uniform)
+            lds_dma16(sel == 0 ? gA : sel == 2 ? gB : gM, src_off[n], slot + (size_t)(wave_piece0 + n * NT) * 16);
         }
         // (two buffers for the means: they ride with the even frame; one buffer: see the head of the frame loop)
     };
@@ -205,8 +211,8 @@ __device__ __forceinline__ void corr_masked_tile(const ModelDev& m, const Masked
             for (int n = 0; n < C::NMU; n++) {
                 // (the source through a local: with the subscript inside the builtin's argument list clang drops the kernel's
                 // host stub without a diagnostic, ROCm 7.2)
-                const UMPA_GLOBAL char* src = gmu + mu_off[n];
-                __builtin_amdgcn_global_load_lds(src, dst + (size_t)(wave_piece0 + n * NT) * 16, 16, 0, 0);
+                const unsigned off = mu_off[n];
+                lds_dma16(gmu, off, dst + (size_t)(wave_piece0 + n * NT) * 16);
             }
         }
     };
