@@ -37,6 +37,8 @@ struct ModelDev {
 struct RegionArgs {
     int org0, step0, N0;       // pixel (xi,xj) sits at frame coords (org0+step0*xi, org1+step1*xj)
     int org1, step1, N1;
+    int pitch;                 // tiled path: pixels per row of the OUTPUT arrays (N1, or the full region's N1 when this is one
+                               // rectangle of it written in place); the general kernels take dense arrays (pitch = N1)
     double* values; int nparam;
     size_t v_px, v_k;          // element (pixel px, parameter k) of `values` sits at px*v_px + k*v_k (interleaved: nparam,1; planar: 1,N0*N1)
     double* uv;                // may be NULL: start at (0,0), result not stored

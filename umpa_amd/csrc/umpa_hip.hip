@@ -488,7 +488,23 @@ hipError_t copy_block(void* dst, int dN1, int dr, int dc, const void* src, int s
 int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0, int r1, int c0, int c1, bool tiled,
               int flags, hipStream_t s, const FrameSubset* sub = nullptr)
 {
-    const bool keep_in = !tiled || sub != nullptr;                    // pixels the kernels may leave untouched: coverage threshold
+    if (tiled) {
+        // the tiled kernels write this rectangle of the full arrays in place (row pitch = the full region's): nothing is
+        // copied, pixels below the coverage threshold keep what they had
+        RegionArgs B = A;
+        const size_t off = (size_t)r0 * A.pitch + c0;
+        B.org0 = A.org0 + A.step0 * r0; B.N0 = r1 - r0;
+        B.org1 = A.org1 + A.step1 * c0; B.N1 = c1 - c0;
+        if (B.N0 <= 0 || B.N1 <= 0) return 0;
+        B.values = A.values + off * A.v_px; B.err = A.err + off;
+        if (A.uv) B.uv = A.uv + 2 * off;
+        if (A.cover) B.cover = A.cover + off;
+        if (A.dbg_d) B.dbg_d = A.dbg_d + 25 * off;
+        if (A.dbg_a) B.dbg_a = A.dbg_a + 16 * off;
+        if (A.dbg_n) B.dbg_n = A.dbg_n + off;
+        return run_tiled(m, B, g, flags, s, 0, nullptr, sub);
+    }
+    const bool keep_in = true;                                        // pixels the kernels may leave untouched: coverage threshold
     const int rows = r1 - r0, cols = c1 - c0;
     if (rows <= 0 || cols <= 0) return 0;
     const size_t n = (size_t)rows * cols, nfull = (size_t)A.N0 * A.N1;
@@ -497,7 +513,7 @@ int run_block(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int r0,
     if (m->t_values.reserve(n * np * sizeof(double)) || m->t_err.reserve(n * sizeof(int))) return fail(UMPA_HIP_E_NOMEM, "block scratch");
     RegionArgs B = A;
     B.org0 = A.org0 + A.step0 * r0; B.N0 = rows;
-    B.org1 = A.org1 + A.step1 * c0; B.N1 = cols;
+    B.org1 = A.org1 + A.step1 * c0; B.N1 = cols; B.pitch = cols;
     B.values = (double*)m->t_values.p; B.err = (int*)m->t_err.p;
     B.v_px = planar ? 1 : (size_t)np; B.v_k = planar ? n : 1;
     B.uv = nullptr; B.cover = nullptr; B.dbg_d = nullptr; B.dbg_a = nullptr; B.dbg_n = nullptr;
@@ -1027,7 +1043,7 @@ int umpa_hip_match_region(umpa_hip_model* m, int start0, int step0, int N0, int 
 
     RegionArgs A;
     A.org0 = m->padding + start0; A.step0 = step0; A.N0 = N0;       // model.pyx:482-483
-    A.org1 = m->padding + start1; A.step1 = step1; A.N1 = N1;
+    A.org1 = m->padding + start1; A.step1 = step1; A.N1 = N1; A.pitch = N1;
     A.nparam = nparam; A.thr = cover_threshold; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0; A.blur_ready = 0;
     const bool planar = (flags & UMPA_HIP_F_PLANAR) != 0;
     A.v_px = planar ? 1 : (size_t)nparam; A.v_k = planar ? n : 1;
@@ -1156,7 +1172,7 @@ int umpa_hip_min(umpa_hip_model* m, int i, int j, double* values, double* uv, do
     hipStream_t s = m->stream;
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
     RegionArgs A;
-    A.org0 = i; A.step0 = 1; A.N0 = 1; A.org1 = j; A.step1 = 1; A.N1 = 1;      // Model::min takes absolute coordinates
+    A.org0 = i; A.step0 = 1; A.N0 = 1; A.org1 = j; A.step1 = 1; A.N1 = 1; A.pitch = 1;      // Model::min takes absolute coordinates
     A.values = d; A.nparam = np; A.v_px = np; A.v_k = 1; A.uv = d + 8; A.err = (int*)(d + 10); A.cover = nullptr; A.thr = 0.0;
     A.dbg_n = (int*)(d + 11); A.dbg_d = d + 12; A.dbg_a = d + 37; A.kern = nullptr; A.kern_stride = 0; A.row_base = 0; A.blur = nullptr; A.blur_F = 0; A.blur_ready = 0;
     if (int rc = run_direct(m, A, s)) return rc;

@@ -497,7 +497,7 @@ replay_cost_kernel(ModelDev m, const double* table, size_t slot_stride, int drow
         xi = row0 + blockIdx.y;
         live = xi < row0 + rows && xj < A.N1;
     }
-    const size_t px = (size_t)xi * A.N1 + xj;
+    const size_t px = (size_t)xi * A.pitch + xj;                        // in the output arrays
     const size_t tpx = (size_t)(xi * A.step0 - drow0) * N1d + (size_t)xj * A.step1;
     if (live && A.cover && gp(A.cover)[px] < A.thr) live = false;
     OdLane L;
@@ -524,7 +524,7 @@ replay_cost_kernel(ModelDev m, const double* table, size_t slot_stride, int drow
             }
             walk_feed(w, memo, st, c, fit, m.call_cap);
         }
-        if (L.miss) od_park(od, L, (int)px);
+        if (L.miss) od_park(od, L, xi * A.N1 + xj);
         else {
             double nb[16];
             walk_finish(w, memo, m.subpx, nb);

@@ -409,7 +409,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         xi = R.row0 + blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
         live = xi < R.row0 + R.rows && xj < A.N1;
     }
-    const size_t px = (size_t)xi * A.N1 + xj;
+    const size_t px = (size_t)xi * A.pitch + xj;                     // in the output arrays
     const size_t tpx = (size_t)(xi * A.step0 - R.drow0) * R.N1d + (size_t)xj * A.step1;
     if (live && A.cover && gp(A.cover)[px] < A.thr) live = false;
     OdLane L;
@@ -486,7 +486,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
             walk_feed(w, memo, st, c, fit, m.call_cap);
         }
     }
-    if (L.miss) od_park(od, L, (int)px);
+    if (L.miss) od_park(od, L, xi * A.N1 + xj);
     else {
         double nb[16];
         walk_finish(w, memo, (R.ablate & 2) ? 0 : m.subpx, nb);
