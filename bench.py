@@ -84,7 +84,13 @@ def collect_kernels(lib, h):
     return kernels
 
 
-def roofline(kernels, steps, abytes, config):
+def useful_fma(K, Nw, ms, N0, N1):
+    """The table kernel's arithmetic without halos or padding: per output pixel and integer shift, K
+    product FMAs and the two 1-D window filters of 2 Nw + 1 taps."""
+    return float(K + 2 * (2 * Nw + 1)) * N0 * N1 * (2 * ms - 1) ** 2
+
+
+def roofline(kernels, steps, abytes, config, useful=None):
     """The dominant kernel against the roofline that bounds it.  corr_volume is fp64-FMA bound:
     `achieved` = the FMAs it actually executes (counted from the launch geometry) x 2 / its duration, against the
     78.6 TFLOP/s fp64 peak.  The HBM figure the contract describes (the whole match's algorithmic bytes / the
@@ -112,6 +118,8 @@ def roofline(kernels, steps, abytes, config):
         out.update(bound="fp64_fma", achieved=round(tf, 3), peak=FP64_PEAK_TF, unit="TFLOP/s", frac=round(tf / FP64_PEAK_TF, 5))
         out["fp64_fma"] = dict(fma_per_launch=fma / max(per_step, 1), achieved_tflops=round(tf, 3), peak_tflops=FP64_PEAK_TF,
                                frac=round(tf / FP64_PEAK_TF, 5),
+                               useful_fma_per_match=useful,
+                               frac_useful=None if not useful or dom != "corr_volume" else round(2.0 * useful / (dur_ms * 1e-3) / 1e12 / FP64_PEAK_TF, 5),
                                note="fp64 issue slots executed by the tiled path's dominant kernel (corr_volume: all FMAs; corr_masked: an "
                                     "FMA, multiply or add each one slot), counted on the host from the launch geometry and the device's "
                                     "count of (tile, pass) units it computed, x2 flop, / its HIP-event duration")
@@ -209,7 +217,10 @@ def main():
     nc = ncalls.cpu().numpy()
     err_h = err.cpu().numpy()
 
-    roof = roofline(kernels, args.steps, algorithmic_bytes(K, H, W, N0, N1, nparam), config)
+    # (the PMC traffic figures belong to a geometry: an overridden frame shape has none, except one rank's slab of C4)
+    tkey = config if not (args.rows or args.cols) else ("C4slab" if (config, args.rows, args.cols) == ("C2", 1042, 8192) else "")
+    roof = roofline(kernels, args.steps, algorithmic_bytes(K, H, W, N0, N1, nparam), tkey,
+                    useful=None if mask is not None else useful_fma(K, Nw, ms, N0, N1))
     cpu = None
     if not args.no_cpu:
         cpu = cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1, mask=mask)
@@ -361,7 +372,8 @@ def sharded(args, world, rank, local, dev, backend):
         agrees = None if args.no_cpu else verify_slab_boundaries(
             world, H, W, K, Nw, ms, df, P, N1, nparam, st_s, whole_v, whole_e, cls, local)
         name = "C4" if (world == 8 and H == 8192 and W == 8192) else "C4-type"
-        roof = roofline(kernels, args.steps, algorithmic_bytes(K, N0 + 2 * P, W, N0, N1, nparam), "C4slab")
+        roof = roofline(kernels, args.steps, algorithmic_bytes(K, N0 + 2 * P, W, N0, N1, nparam), "C4slab",
+                        useful=useful_fma(K, Nw, ms, N0, N1))
         out = {
             "metric": "Mpixels/s (output map) at Nw=%d, max_shift=%d, %d frames" % (Nw, ms, K),
             "value": round(npx * args.steps / dt / 1e6, 3),
