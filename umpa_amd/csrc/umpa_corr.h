@@ -137,7 +137,10 @@ struct CorrCfg {
     // row filter's lanes (one column each) read 16-byte aligned row pairs (ds_read_b128), 16 lanes of a group in 16
     // different 16-byte slots of the 256-byte bank row
     static constexpr int HQP = QR + ((6 - QR % 4) % 4);
-    static constexpr int HPL = TC * HQP;
+    // plane pitch = QR (mod 32), as PPL: the column filter's lanes run over the rows of one (plane, column block) after the
+    // other and write their results at this pitch -- the bank sequence continues across the seam (32x32 tiles at window 11:
+    // TC * HQP = 0 mod 32 put the lanes after the seam on the banks of the lanes before it)
+    static constexpr int HPL = TC * HQP + ((QR - TC * HQP) % 32 + 32) % 32;
     static constexpr int FLUSH = PR * PPL + (RO > 1 ? PR * HPL : 0);
     static constexpr int LDS_DOUBLES = RING > FLUSH ? RING : FLUSH;
     static constexpr size_t LDS = (size_t)LDS_DOUBLES * sizeof(double);
