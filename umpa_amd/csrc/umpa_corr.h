@@ -117,7 +117,17 @@ struct CorrCfg {
     static constexpr int NQB = (QC + QB - 1) / QB;        // column blocks
     static constexpr int NBP = (QB + UB) / 2;             // B column pairs a thread reads: ceil((QB+UB-1)/2)
     static constexpr int BW = (QC + UB) & ~1;             // B columns staged, even
-    static constexpr int PA = (QC / 2) | 1, PB = (BW / 2) | 1;   // 16-byte pieces per image row: odd
+    // 16-byte pieces per image row: odd (16 consecutive rows of one column block then sit in 16 different 16-byte slots), and
+    // -- where the window allows it -- QR * pitch = QB / 2 (mod 16): the lanes of a ds_read_b128 group that straddle two column
+    // blocks (rows wrap from QR - 1 to 0, the piece index steps by QB / 2) then continue the slot sequence.  Measured
+    // (tools/microbench/lds_b128_pitch.hip): 42 rows at pitch 21: no conflict cycles, at pitch 25: 40 % of the LDS-active cycles.
+    static constexpr int pitch_for(int least)
+    {
+        for (int p = least | 1; p < (least | 1) + 16; p += 2)
+            if ((QR * p) % 16 == (QB / 2) % 16) return p;
+        return least | 1;                                 // (even half-window: no such pitch)
+    }
+    static constexpr int PA = pitch_for(QC / 2), PB = pitch_for(BW / 2);
     // pieces of one staged frame: A image, then B image from a multiple of 64 pieces on -- a wave-instruction (64 pieces)
     // then reads one stack only, and its base address is a scalar (SGPR base + 32-bit lane offset)
     static constexpr int APIECES = (QR * PA + 63) & ~63;
