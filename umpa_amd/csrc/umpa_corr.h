@@ -75,6 +75,8 @@ struct CorrArgs {
     int org0, org1;           // frame coordinates of output pixel (0,0) of the REGION
     int row0, rows;           // this launch covers region rows [row0, row0+rows)
     int N1;
+    int pitch;                // doubles per table row: N1 rounded up to whole 256-byte tile rows (every tile's store instructions then
+                              // write whole, aligned 128-byte lines: tools/microbench/table_store_rate.hip), columns N1 .. pitch-1 padding
     int sigma;                // +1: B = ref sits at p+u ('sam' mode); -1: B = sam sits at p-u ('ref' mode)
     int ntx, nty;
     int br0, br1, bc0, bc1, Wf;   // rows / columns of the image inside every frame, the frames' common width (Maps, umpa_tiled.h)
@@ -402,7 +404,7 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
     // LDS (transposed, [column][row]), filters them along the columns in place and along the rows on the way out.
     const int nu = min(UB, ms - oj0);                                 // column offsets oj0 .. oj0+nu-1 are real
     constexpr int PR = C::PR, VITEMS2 = PR * (C::TR / C::CB) * TC, VROUNDS2 = (VITEMS2 + NT - 1) / NT;
-    const bool vec_ok = (A.N1 & 1) == 0;
+    const bool vec_ok = (A.pitch & 1) == 0;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
         // frames (or the previous round's planes) consumed.  RO > 1: the raw planes were last read before the barrier in
@@ -448,7 +450,7 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
             // N1, take the general code.
             // (a plane takes 32 lanes per row block, also on narrower tiles, where the lanes past the last column idle)
             static_assert(PR * (C::TR / C::CB) * 32 <= NT && TC <= 32 && TC % 2 == 0, "one item per thread, plane per two waves");
-            const bool inside = prow0 + C::TR <= A.row0 + A.rows && pcol0 + TC <= A.N1 && vec_ok && !(A.ablate & 16);
+            const bool inside = prow0 + C::TR <= A.row0 + A.rows && pcol0 + TC <= A.pitch && vec_ok && !(A.ablate & 16);
             if (inside) {
                 const int pl = __builtin_amdgcn_readfirstlane(tid / (32 * (C::TR / C::CB)));
                 const int P = f * PR + pl, g = P / UB, u = P - g * UB;
@@ -459,14 +461,14 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
                                            1, sep.hr, out);
                     const int ui = A.sigma * (oi0 + g), uj = A.sigma * (oj0 + u);
                     const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
-                    UMPA_GLOBAL double* sbase = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 - A.row0) * A.N1 + pcol0;   // scalar
-                    const unsigned voff = (unsigned)((rb * C::CB + odd) * A.N1 + c - odd) * 8u;     // this lane's bytes from there
+                    UMPA_GLOBAL double* sbase = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 - A.row0) * A.pitch + pcol0;   // scalar
+                    const unsigned voff = (unsigned)((rb * C::CB + odd) * A.pitch + c - odd) * 8u;     // this lane's bytes from there
 #pragma unroll
                     for (int h = 0; h < C::CB / 2; h++) {
                         const double give = odd ? out[2 * h] : out[2 * h + 1];
                         const double got = swap_adjacent_lanes(give);
                         pair_t v2; v2[0] = odd ? got : out[2 * h]; v2[1] = odd ? out[2 * h + 1] : got;
-                        UMPA_GLOBAL char* rowp = reinterpret_cast<UMPA_GLOBAL char*>(sbase + (size_t)(2 * h) * A.N1);
+                        UMPA_GLOBAL char* rowp = reinterpret_cast<UMPA_GLOBAL char*>(sbase + (size_t)(2 * h) * A.pitch);
                         __builtin_nontemporal_store(v2, reinterpret_cast<UMPA_GLOBAL table_pair_t*>(rowp + voff));
                     }
                 }
@@ -517,7 +519,7 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
                     const int ui = A.sigma * (oi0 + g), uj = A.sigma * (oj0 + u);
                     const size_t slot = (size_t)(ui + ms - 1) * UJ + (uj + ms - 1);
                     const int col = pcol0 + c;
-                    UMPA_GLOBAL double* dst = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 + rb * C::CB - A.row0) * A.N1 + col;
+                    UMPA_GLOBAL double* dst = gpw(A.table) + slot * A.slot_stride + (size_t)(prow0 + rb * C::CB - A.row0) * A.pitch + col;
                     if (vec_ok) {
                         const int odd = c & 1;
 #pragma unroll
@@ -526,15 +528,15 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
                             const double give = odd ? out[2 * h] : out[2 * h + 1];
                             const double got = swap_adjacent_lanes(give);           // the neighbour column's value of MY row
                             const int o = 2 * h + odd, row = prow0 + rb * C::CB + o;
-                            if (row < A.row0 + A.rows && col < A.N1 && !(A.ablate & 16)) {     // (ablation 16: everything but the table stores)
+                            if (row < A.row0 + A.rows && col < A.pitch && !(A.ablate & 16)) {     // (ablation 16: everything but the table stores)
                                 pair_t v2; v2[0] = odd ? got : mine; v2[1] = odd ? mine : got;
-                                store_table16(dst + (size_t)o * A.N1 - odd, v2);
+                                store_table16(dst + (size_t)o * A.pitch - odd, v2);
                             }
                         }
                     } else {
 #pragma unroll
                         for (int o = 0; o < C::CB; o++)
-                            if (prow0 + rb * C::CB + o < A.row0 + A.rows && col < A.N1) dst[(size_t)o * A.N1] = out[o];
+                            if (prow0 + rb * C::CB + o < A.row0 + A.rows && col < A.N1) dst[(size_t)o * A.pitch] = out[o];
                     }
                 }
             }

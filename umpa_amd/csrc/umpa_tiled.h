@@ -201,7 +201,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides, int
 struct ReplayArgs {
     const double* table;      // [(2ms-1)^2][drows][N1d]: the DENSE (unit-step) grid under the requested region
     size_t slot_stride;       // drows * N1d
-    int drow0, N1d;           // first dense row held by the table, dense row length
+    int drow0, N1d;           // first dense row held by the table, doubles per table row (the dense row length, padded: CorrArgs::pitch)
     int row0, rows;           // OUTPUT rows [row0, row0+rows) whose dense rows the table holds
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE_REPLAY): 1 = 18 fixed lookups instead of the walk, 2 = no sub-pixel fit
 };
@@ -918,7 +918,11 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     // (tiled_applicable only sends small steps here).  Rows per chunk: the shift table of one chunk stays within
     // the budget (whole tiles).
     const int N0d = A.step0 * (A.N0 - 1) + 1, N1d = A.step1 * (A.N1 - 1) + 1;
-    const size_t row_bytes = (size_t)UJ * UJ * N1d * sizeof(double);
+    // table rows are padded to whole 256-byte tile rows: every (tile, row) of a plane is then a run of whole, aligned
+    // 128-byte lines (C2: 2028 -> 2048 doubles; UMPA_HIP_TABLE_ALIGN=1 packs the rows as round 3 did)
+    static const int table_align = getenv("UMPA_HIP_TABLE_ALIGN") ? std::max(1, atoi(getenv("UMPA_HIP_TABLE_ALIGN"))) : 32;
+    const int N1p = (N1d + table_align - 1) / table_align * table_align;
+    const size_t row_bytes = (size_t)UJ * UJ * N1p * sizeof(double);
     long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
     if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
     if (rows_chunk > N0d) rows_chunk = ((long)N0d + UMPA_TILE - 1) / UMPA_TILE * UMPA_TILE;
@@ -927,15 +931,15 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         if (want < rows_chunk) rows_chunk = want;
     }
     {   // eval_lookup multiplies the slot number by a 32-bit slot stride (rows_chunk * N1d)
-        const long cap = (long)(0xffffffffull / (size_t)N1d) / UMPA_TILE * UMPA_TILE;
+        const long cap = (long)(0xffffffffull / (size_t)N1p) / UMPA_TILE * UMPA_TILE;
         if (cap < UMPA_TILE) return (int)hipErrorInvalidValue;
         if (rows_chunk > cap) rows_chunk = cap;
     }
     if (st.table_limited && st.table_cap > 0) {                        // an earlier allocation of the full budget failed: live with what we got
-        const long fit = (long)(st.table_cap / ((size_t)UJ * UJ * N1d)) / UMPA_TILE * UMPA_TILE;
+        const long fit = (long)(st.table_cap / ((size_t)UJ * UJ * N1p)) / UMPA_TILE * UMPA_TILE;
         if (fit >= UMPA_TILE && fit < rows_chunk) rows_chunk = fit;
     }
-    size_t table_need = (size_t)UJ * UJ * rows_chunk * N1d;
+    size_t table_need = (size_t)UJ * UJ * rows_chunk * N1p;
     if (st.table_cap < table_need) {
         if (st.table) (void)hipFree(st.table);
         st.table = nullptr; st.table_cap = 0;
@@ -946,7 +950,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
             if (rows_chunk <= UMPA_TILE) return -3;
             st.table_limited = true;
             rows_chunk = std::max<long>(UMPA_TILE, rows_chunk / 2 / UMPA_TILE * UMPA_TILE);
-            table_need = (size_t)UJ * UJ * rows_chunk * N1d;
+            table_need = (size_t)UJ * UJ * rows_chunk * N1p;
         }
         st.table_cap = table_need;
     }
@@ -988,7 +992,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     for (int drow0 = 0; drow0 < N0d; drow0 += (int)rows_chunk) {
         const int drows = (int)((N0d - drow0 < rows_chunk) ? N0d - drow0 : rows_chunk);
         CorrArgs CA;
-        CA.table = st.table; CA.slot_stride = (size_t)drows * N1d;
+        CA.table = st.table; CA.slot_stride = (size_t)drows * N1p; CA.pitch = N1p;
         CA.org0 = A.org0; CA.org1 = A.org1; CA.row0 = drow0; CA.rows = drows; CA.N1 = N1d;
         CA.sigma = dev.ref_mode ? -1 : 1;
         CA.br0 = box.r0; CA.br1 = box.r1; CA.bc0 = box.c0; CA.bc1 = box.c1 + box.slack; CA.Wf = box.Wf;   // (pairs may start on column c1 then)
@@ -998,7 +1002,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         const int xi_lo = (drow0 + A.step0 - 1) / A.step0;
         const int xi_hi = std::min(A.N0, (drow0 + drows - 1) / A.step0 + 1);
         ReplayArgs R;
-        R.table = st.table; R.slot_stride = CA.slot_stride; R.drow0 = drow0; R.N1d = N1d;
+        R.table = st.table; R.slot_stride = CA.slot_stride; R.drow0 = drow0; R.N1d = N1p;
         R.row0 = xi_lo; R.rows = std::max(0, xi_hi - xi_lo);
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
         // frame count as a template constant where the map planes are 32-bit addressable (eval_lookup)
