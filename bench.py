@@ -90,23 +90,30 @@ def useful_fma(K, Nw, ms, N0, N1):
     return float(K + 2 * (2 * Nw + 1)) * N0 * N1 * (2 * ms - 1) ** 2
 
 
-def roofline(kernels, steps, abytes, config, useful=None):
-    """The dominant kernel against the roofline that bounds it.  corr_volume is fp64-FMA bound:
-    `achieved` = the FMAs it actually executes (counted from the launch geometry) x 2 / its duration, against the
-    78.6 TFLOP/s fp64 peak.  The HBM figure the contract describes (the whole match's algorithmic bytes / the
-    dominant kernel's duration, against 8 TB/s) sits beside it under "hbm"; `traffic` = PMC bytes per launch."""
+def roofline(kernels, steps, abytes, config, useful=None, ms_per_step=None):
+    """The dominant kernel against the roofline that bounds it.  The table kernel is fp64-FMA bound.
+    `achieved` / `frac` price the ALGORITHMIC arithmetic of the restructured algorithm -- `useful`, per output pixel and integer
+    shift K products + two (2 Nw + 1)-tap window filters, no halos, no padding -- x 2 flop / the kernel's HIP-event duration,
+    against the 78.6 TFLOP/s fp64 peak.  What the kernel EXECUTES (halo and padding included, counted on the host from the
+    launch geometry) sits beside it as `frac_executed`.  Models with masks have no closed count of useful arithmetic: there
+    `frac` is the executed figure and `frac_executed` says the same.  The HBM figure the contract describes (the whole match's
+    algorithmic bytes / the dominant kernel's duration, against 8 TB/s) sits under "hbm"; `traffic` = PMC bytes per launch.
+    `step`: the whole step -- useful TFLOP/s and the counter traffic of all its kernels over `ms_per_step`."""
     if not kernels:
         return None
     dom = max(kernels, key=lambda k: kernels[k][0] * kernels[k][1])
     per_step = kernels[dom][1] / steps
     dur_ms = kernels[dom][0] * per_step
-    traffic = None
+    traffic, traffic_all = None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get(config, {}).get(dom)
+            tj = json.load(open(tp)).get(config, {})
+            traffic = tj.get(dom)
+            per = {k: tj[k] * kernels[k][1] / steps for k in kernels if isinstance(tj.get(k), (int, float))}
+            traffic_all = sum(per.values()) if len(per) == len(kernels) else None
         except Exception:
-            traffic = None
+            traffic = traffic_all = None
     gbs = abytes / (dur_ms * 1e-3) / 1e9
     hbm = dict(achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5),
                algorithmic_bytes=abytes)
@@ -114,17 +121,33 @@ def roofline(kernels, steps, abytes, config, useful=None):
     out = dict(kernel=dom, kernel_ms=round(dur_ms, 4), traffic=traffic,
                kernels_ms={k: round(v[0] * v[1] / steps, 4) for k, v in kernels.items()}, hbm=hbm)
     if fma > 0:
-        tf = 2.0 * fma / (dur_ms * 1e-3) / 1e12
-        out.update(bound="fp64_fma", achieved=round(tf, 3), peak=FP64_PEAK_TF, unit="TFLOP/s", frac=round(tf / FP64_PEAK_TF, 5))
-        out["fp64_fma"] = dict(fma_per_launch=fma / max(per_step, 1), achieved_tflops=round(tf, 3), peak_tflops=FP64_PEAK_TF,
-                               frac=round(tf / FP64_PEAK_TF, 5),
-                               useful_fma_per_match=useful,
-                               frac_useful=None if not useful or dom != "corr_volume" else round(2.0 * useful / (dur_ms * 1e-3) / 1e12 / FP64_PEAK_TF, 5),
-                               note="fp64 issue slots executed by the tiled path's dominant kernel (corr_volume: all FMAs; corr_masked: an "
-                                    "FMA, multiply or add each one slot), counted on the host from the launch geometry and the device's "
-                                    "count of (tile, pass) units it computed, x2 flop, / its HIP-event duration")
+        tf_exec = 2.0 * fma / (dur_ms * 1e-3) / 1e12
+        have_useful = bool(useful) and dom == "corr_volume"
+        tf = 2.0 * useful / (dur_ms * 1e-3) / 1e12 if have_useful else tf_exec
+        out.update(bound="fp64_fma", achieved=round(tf, 3), peak=FP64_PEAK_TF, unit="TFLOP/s", frac=round(tf / FP64_PEAK_TF, 5),
+                   frac_executed=round(tf_exec / FP64_PEAK_TF, 5),
+                   priced="algorithmic (useful) fp64 FMAs" if have_useful else "executed fp64 issue slots (no closed useful count for this model)")
+        out["fp64_fma"] = dict(useful_fma_per_match=useful if have_useful else None,
+                               executed_fma_per_launch=fma / max(per_step, 1), executed_tflops=round(tf_exec, 3),
+                               peak_tflops=FP64_PEAK_TF,
+                               note="useful: (K + 2 (2 Nw + 1)) (2 ms - 1)^2 N0 N1 FMAs per match; executed: fp64 issue slots of the tiled "
+                                    "path's dominant kernel (corr_volume: all FMAs incl. halo and padding; corr_masked: an FMA, multiply "
+                                    "or add each one slot), counted on the host from the launch geometry and the device's count of "
+                                    "(tile, pass) units it computed; x2 flop, / the kernel's HIP-event duration")
     else:
         out.update(bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"])
+    if ms_per_step:
+        st = dict(ms=round(ms_per_step, 4),
+                  algorithmic_gbs=round(abytes / (ms_per_step * 1e-3) / 1e9, 2),
+                  algorithmic_hbm_frac=round(abytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
+        if useful:
+            st["useful_tflops"] = round(2.0 * useful / (ms_per_step * 1e-3) / 1e12, 3)
+            st["useful_fp64_frac"] = round(st["useful_tflops"] / FP64_PEAK_TF, 5)
+        if traffic_all:
+            st["counter_traffic_bytes"] = int(traffic_all)
+            st["counter_gbs"] = round(traffic_all / (ms_per_step * 1e-3) / 1e9, 1)
+            st["counter_over_algorithmic"] = round(traffic_all / abytes, 2)
+        out["step"] = st
     return out
 
 
@@ -142,11 +165,15 @@ def main():
     backend = os.environ.get("UMPA_BENCH_BACKEND", "nccl")
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that never shows up ends the job after this long instead of holding it (the default is 10 minutes per
+        # collective under RCCL); the per-phase deadlines of the steps are sharding.Watchdog's
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("UMPA_BENCH_PG_TIMEOUT", "180")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=pg_timeout)
     assert world == args.gpus or world == 1 and args.gpus == 1, \
         "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
@@ -220,7 +247,7 @@ def main():
     # (the PMC traffic figures belong to a geometry: an overridden frame shape has none, except one rank's slab of C4)
     tkey = config if not (args.rows or args.cols) else ("C4slab" if (config, args.rows, args.cols) == ("C2", 1042, 8192) else "")
     roof = roofline(kernels, args.steps, algorithmic_bytes(K, H, W, N0, N1, nparam), tkey,
-                    useful=None if mask is not None else useful_fma(K, Nw, ms, N0, N1))
+                    useful=None if mask is not None else useful_fma(K, Nw, ms, N0, N1), ms_per_step=dt / args.steps * 1e3)
     cpu = None
     if not args.no_cpu:
         cpu = cpu_baseline(m, sam, ref, Nw, ms, df, N0, N1, mask=mask)
@@ -258,6 +285,14 @@ def sharded(args, world, rank, local, dev, backend):
 
     cfg = dict(CONFIGS["C4"])
     K, Nw, ms, df = cfg["K"], cfg["Nw"], cfg["max_shift"], cfg["df"]
+    # which GPU every rank sits on (stderr, one line per rank; rank 0 puts the list into the JSON line), and a watchdog:
+    # a rank wedged in the halo exchange, the match or the gather ends with exit code 3 instead of hanging the run
+    me = "rank %d/%d local %d: %s" % (rank, world, local, sharding.describe_device(local))
+    print("[bench] " + me, file=sys.stderr, flush=True)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    wd = sharding.Watchdog(rank=rank)
+    phase_s = float(os.environ.get("UMPA_BENCH_PHASE_TIMEOUT", "120"))
     H = world * (args.rows or BLOCK_ROWS)
     W = args.cols or cfg["W"]
     P = Nw + ms
@@ -307,6 +342,10 @@ def sharded(args, world, rank, local, dev, backend):
     cb = _lib.ROWS_FN(on_rows)
 
     def step(marks=None, with_ncalls=False):
+        with wd.phase("step (halo exchange, match, gather)", phase_s):
+            _step(marks, with_ncalls)
+
+    def _step(marks=None, with_ncalls=False):
         nonlocal overlap
         if marks: marks[0].record()
         sharding.exchange_halos([st_s, st_r])
@@ -330,9 +369,10 @@ def sharded(args, world, rank, local, dev, backend):
         if marks: marks[3].record()
 
     def fence():
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
+        with wd.phase("barrier", phase_s):
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
 
     # self-check of the piecewise gather on the first (untimed) step: every row of the whole maps must have arrived on
     # rank 0; if not, every rank falls back to the gather after the match
@@ -373,7 +413,7 @@ def sharded(args, world, rank, local, dev, backend):
             world, H, W, K, Nw, ms, df, P, N1, nparam, st_s, whole_v, whole_e, cls, local)
         name = "C4" if (world == 8 and H == 8192 and W == 8192) else "C4-type"
         roof = roofline(kernels, args.steps, algorithmic_bytes(K, N0 + 2 * P, W, N0, N1, nparam), "C4slab",
-                        useful=useful_fma(K, Nw, ms, N0, N1))
+                        useful=useful_fma(K, Nw, ms, N0, N1), ms_per_step=dt / args.steps * 1e3)   # (rank 0's slab over the whole step)
         out = {
             "metric": "Mpixels/s (output map) at Nw=%d, max_shift=%d, %d frames" % (Nw, ms, K),
             "value": round(npx * args.steps / dt / 1e6, 3),
@@ -388,7 +428,7 @@ def sharded(args, world, rank, local, dev, backend):
                                        name, H, W, K, Nw, ms, "on" if df else "off", H // world, H // world, W),
                        "output_pixels_total": npx, "output_pixels_per_gpu": N0 * N1, "kernel_path": path,
                        "parallelism": "rows x%d" % world, "comm_backend": "rccl" if backend == "nccl" else backend,
-                       "rccl_world_size": world,
+                       "rccl_world_size": dist.get_world_size(), "devices": everyone,
                        "halo_ms": round(float(tmax[1]), 4), "match_ms": round(float(tmax[2]), 4),
                        "gather_ms": round(float(tmax[3]), 4),
                        "gather_mode": "row pieces of %d rows sent while the next piece is matched; gather_ms is what is left "

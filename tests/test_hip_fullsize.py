@@ -148,3 +148,90 @@ def test_C3_parameters_at_1536_multi_chunk_table(port_ns, monkeypatch):
     for r0, r1 in bands:
         got = {k: (v[r0:r1] if isinstance(v, np.ndarray) and v.shape[:1] == (N0,) else v) for k, v in a.items()}
         assert_parity(got, want[r0], ms, "C3 params 1536 rows %d-%d" % (r0, r1))
+
+
+def test_C3_full_size_default_and_chunked_table(port_ns, monkeypatch):
+    """BASELINE config C3 at its full size (4096 x 4096, 20 frames, Nw=7, max_shift=8, dark-field on): the whole image with
+    the default table budget (two row chunks) and with a 4 GiB budget (eight): identical maps; three 2-row bands of full
+    width -- first rows, a chunk seam region, last rows -- against the CPU oracle, matched as ROIs (with the debug arrays the
+    parity rules classify by) and read out of the whole-image maps."""
+    from conftest import assert_parity
+    from umpa_amd import model
+    from umpa_amd.synth import make_stack
+    Nw, ms, K, n = 7, 8, 20, 4096
+    sam, ref, _ = make_stack(n, n, K, ms, df=True, seed=11, order=1)
+    m = model.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms)
+    m.debug = "ncalls"
+    N0, N1 = m.extent
+    assert (N0, N1) == (4066, 4066)
+    a = m.match(quiet=True)
+    assert m._lib.last_path(m._handle) == 2
+    monkeypatch.setenv("UMPA_HIP_TABLE_MB", "4096")
+    b = m.match(quiet=True)
+    monkeypatch.delenv("UMPA_HIP_TABLE_MB")
+    for k in ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    del b
+    assert a["err"].mean() > 0.9
+    bands = [(0, 2), (2303, 2305), (N0 - 2, N0)]                    # (2304 = the default budget's chunk seam at this width)
+    want = _oracle_rows(port_ns, "UMPAModelDF", sam, ref, Nw, ms, bands)
+    m.debug = True
+    for r0, r1 in bands:
+        got = m.match(ROI=((r0, r1, 1), (0, N1, 1)), quiet=True)
+        assert_parity(got, want[r0], ms, "C3 full size rows %d-%d" % (r0, r1))
+        for k in ("f", "T", "dx", "dy", "df", "err", "debug_Ncalls"):     # the whole-image match holds the same numbers
+            np.testing.assert_array_equal(a[k][r0:r1], got[k], err_msg="%s rows %d-%d" % (k, r0, r1))
+
+
+def test_C5_projection_full_size_through_the_streaming_matcher(port_ns):
+    """One projection of BASELINE config C5 at its full size (2048 x 2048, 5 frames, Nw=5, max_shift=5, dark-field on) through
+    StreamingMatcher -- uint16 counts, flat / dark correction fused into the upload, asynchronous match, maps in page-locked
+    memory -- against the CPU oracle on (proj - dark) / flat, a 64-row band of full width; and twice in a row (the second
+    projection reuses the reference-side maps)."""
+    from conftest import assert_parity
+    from umpa_amd.farm import StreamingMatcher
+    from umpa_amd.synth import make_stack
+    Nw, ms, K, n = 5, 5, 5, 2048
+    sam, ref, _ = make_stack(n, n, K, ms, df=True, seed=21, order=1)
+    rng = np.random.default_rng(5)
+    dark = 100.0 + rng.uniform(0, 2, size=(K, n, n))
+    flat = 20000.0 * (1.0 + 0.05 * rng.standard_normal((K, n, n)))
+    raws = [np.rint(np.roll(sam, p, axis=2) * flat + dark).astype(np.uint16) for p in range(2)]
+    sm = StreamingMatcher(ref[None], Nw, ms, df=True, device=0, flats=flat[None], dark=dark, ref_nums=[0], debug=True)
+    bufs = []
+    for r in raws:
+        bufs.append(sm.input_buffer(np.uint16))
+        bufs[-1][...] = r
+    N1 = n - 2 * (Nw + ms)
+    r0, r1 = 980, 1044
+    for pid, res in sm.run(enumerate(bufs)):
+        corrected = (raws[pid].astype(np.float64) - dark) / flat
+        o = port_ns.UMPAModelDF(corrected, ref, window_size=Nw, max_shift=ms)
+        o.debug = True
+        want = o.match(ROI=((r0, r1, 1), (0, N1, 1)), quiet=True)
+        got = {k: (v[r0:r1] if isinstance(v, np.ndarray) else v) for k, v in res.items()}
+        st = assert_parity(got, want, ms, "C5 full size p%d" % pid)
+        assert st["ok"] > 0.9 * 64 * N1
+
+
+def test_streaming_matcher_survives_an_abandoned_series(port_ns):
+    """A consumer that leaves StreamingMatcher.run() early (break) leaves matches in flight; the generator's clean-up waits
+    for them, so that the next series on the same matcher pairs every wait with its own match: the second
+    series' maps equal those of a fresh matcher bit for bit."""
+    from umpa_amd.farm import StreamingMatcher
+    from umpa_amd.synth import make_stack
+    Nw, ms, K, n = 3, 4, 3, 256
+    sam, ref, _ = make_stack(n, n, K, ms, df=True, seed=31, order=1)
+    projs = [np.ascontiguousarray(np.roll(sam, p, axis=2)) for p in range(5)]
+    sm = StreamingMatcher(ref[None], Nw, ms, df=True, device=0)
+    for pid, res in sm.run(enumerate(projs)):
+        break                                                       # two matches are in flight at this point
+    second = {pid: {k: np.array(v) for k, v in res.items() if isinstance(v, np.ndarray)} for pid, res in sm.run(enumerate(projs))}
+    fresh = StreamingMatcher(ref[None], Nw, ms, df=True, device=0)
+    first = {pid: {k: np.array(v) for k, v in res.items() if isinstance(v, np.ndarray)} for pid, res in fresh.run(enumerate(projs))}
+    assert sorted(second) == sorted(first) == list(range(5))
+    for pid in first:
+        for k in first[pid]:
+            np.testing.assert_array_equal(second[pid][k], first[pid][k], err_msg="p%d %s" % (pid, k))
+    sync = sm.model.match(quiet=True)                               # and the model takes a synchronous match again
+    assert sync["err"].shape == first[0]["err"].shape

@@ -114,3 +114,47 @@ def test_degenerate_sizes(port_ns):
     assert m.extent == (1, 1)
     r = m.match(quiet=True)
     assert r["f"].shape == (1, 1) and r["err"].dtype == np.int32
+
+
+def test_checker_geometry_is_its_own_and_agrees_with_the_candidates(port_ns):
+    """oracle/cpu_model.py computes extent, ROI / step / slice conversion and pixel counts itself (the
+    checker must not share that layer with the candidate).  The two implementations are compared on random forms -- tuples,
+    slices with negative / open bounds, steps, set_step -- and on sample-stepping extents."""
+    from umpa_amd import model
+    rng = np.random.default_rng(12)
+    cand_cls, chk_cls = model.UMPAModelDF, port_ns.UMPAModelDF
+    assert chk_cls._calculate_extent is not cand_cls._calculate_extent and chk_cls._counts is not cand_cls._counts
+    assert chk_cls._convert_ROI_slice is not cand_cls._convert_ROI_slice and chk_cls._set_ROI is not cand_cls._set_ROI
+
+    def host(cls, pos, shapes, padding):                            # the state the geometry methods read, without a native model
+        h = object.__new__(type("Host", (cls,), {"__del__": lambda self: None}))
+        h._pos_list, h._shape_list, h._padding = pos, shapes, padding
+        h._set_ROI(None)
+        return h
+
+    for trial in range(200):
+        K = int(rng.integers(1, 5))
+        pos = rng.integers(0, 9, size=(K, 2)); pos -= pos.min(axis=0)
+        shapes = [(int(rng.integers(40, 70)), int(rng.integers(40, 70))) for _ in range(K)]
+        pad = int(rng.integers(2, 9))
+        a, b = host(cand_cls, [tuple(p) for p in pos], shapes, pad), host(chk_cls, [tuple(p) for p in pos], shapes, pad)
+        assert a._calculate_extent() == b._calculate_extent()
+        n0, n1 = a._calculate_extent()
+
+        def rnd(n):
+            if rng.random() < 0.5:
+                lo = int(rng.integers(0, n - 2)); hi = int(rng.integers(lo + 1, n + 1))
+                return (lo, hi, int(rng.integers(1, 5)))
+            pick = lambda: None if rng.random() < 0.3 else int(rng.integers(-n, n + 3))
+            return slice(pick(), pick(), int(rng.integers(1, 5)))
+        roi = (rnd(n0), rnd(n1))
+        ra, rb = a._convert_ROI_slice(ROI=roi), b._convert_ROI_slice(ROI=roi)
+        assert [len(range(*t)) for t in ra] == [len(range(*t)) for t in rb], (roi, ra, rb)
+        assert [list(range(*t))[:3] for t in ra] == [list(range(*t))[:3] for t in rb], (roi, ra, rb)
+        if all(len(range(*t)) for t in ra):
+            assert cand_cls._counts(*ra) == chk_cls._counts(*rb) == tuple(len(range(*t)) for t in ra)
+        step = int(rng.integers(1, 6))
+        sa, sb = a._convert_ROI_slice(step=step), b._convert_ROI_slice(step=step)
+        assert [list(range(*t)) for t in sa] == [list(range(*t)) for t in sb]
+        a._set_ROI(roi); b._set_ROI(roi)
+        assert [list(range(*t)) for t in a._ROI] == [list(range(*t)) for t in b._ROI]

@@ -4,6 +4,7 @@ gloo backend, world_size 2 and 3.  The pixel work itself is done by the CPU orac
 this leg); what is tested is the partitioning, the halo arithmetic, the neighbour halo exchange and
 the gather -- the sharded result must equal the unsharded one bit for bit.
 """
+import functools
 import os
 import socket
 import sys
@@ -12,6 +13,8 @@ import time
 
 import numpy as np
 import pytest
+
+import farm_cpu_worker
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -130,11 +133,11 @@ def test_projection_farm_failure_modes():
     Nw, ms = 2, 3
     sam, ref, _ = make_stack(40, 44, 3, ms, df=True, seed=7, amplitude=1.0)
     t0 = time.time()
-    with ProjectionFarm(ref, Nw, ms, devices=[None, None], model=("no_such_module_anywhere", "X")) as farm:
+    with ProjectionFarm(ref, Nw, ms, devices=[None, None], worker=functools.partial(farm_cpu_worker.run, model=("no_such_module_anywhere", "X"))) as farm:
         with pytest.raises(RuntimeError, match="farm worker|exited"):
             dict(farm.map([(0, sam), (1, sam)], timeout=60.0))
     assert time.time() - t0 < 60.0
-    with ProjectionFarm(ref, Nw, ms, devices=[None], model=("oracle.cpu_model", "port.UMPAModelDF")) as farm:
+    with ProjectionFarm(ref, Nw, ms, devices=[None], worker=farm_cpu_worker.run) as farm:
         got = list(farm.map([(5, sam), (5, 0.5 * sam), (5, sam)], num_threads=1))       # the same id three times
         assert [g[0] for g in got] == [5, 5, 5]
         want = cpu_model.port.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
@@ -142,6 +145,29 @@ def test_projection_farm_failure_modes():
         with pytest.raises(ValueError, match="full-extent"):
             dict(farm.map([(0, sam)], step=2))
         assert dict(farm.map([(9, sam)], num_threads=1))[9]["T"].shape == want["T"].shape   # still usable afterwards
+
+
+def test_projection_farm_keeps_its_books_when_a_projection_fails():
+    """a projection that fails in its worker ends map() with ProjectionFailed -- AFTER the projections that
+    were in flight beside it have been collected and handed out; the next map() on the same farm sees its own results only."""
+    from oracle import cpu_model
+    from umpa_amd.farm import ProjectionFailed, ProjectionFarm
+    from umpa_amd.synth import make_stack
+    cpu_model.native("port")
+    Nw, ms = 2, 3
+    sam, ref, _ = make_stack(40, 44, 3, ms, df=True, seed=7, amplitude=1.0)
+    worker = functools.partial(farm_cpu_worker.run, fail_pids=(1,))
+    with ProjectionFarm(ref, Nw, ms, devices=[None, None], worker=worker, depth=2) as farm:
+        seen = []
+        with pytest.raises(ProjectionFailed, match="projection 1 failed"):
+            for pid, res in farm.map([(0, sam), (1, sam), (2, 0.5 * sam), (3, sam)], num_threads=1):
+                seen.append(pid)
+        assert 1 not in seen and all(w["inflight"] == 0 for w in farm._workers) and not farm._by_seq
+        got = dict(farm.map([(10, sam), (11, 0.5 * sam)], num_threads=1))
+        assert sorted(got) == [10, 11]
+        want = cpu_model.port.UMPAModelDF(sam, ref, window_size=Nw, max_shift=ms).match(quiet=True, num_threads=1)
+        np.testing.assert_array_equal(got[10]["T"], want["T"])
+        assert not np.array_equal(got[11]["T"], want["T"])
 
 
 def test_projection_farm_on_cpu_workers():
@@ -154,7 +180,7 @@ def test_projection_farm_on_cpu_workers():
     stacks = [make_stack(40, 44, 3, ms, df=True, seed=100 * p, amplitude=1.0) for p in range(3)]
     ref = stacks[0][1]
     sams = {p: np.ascontiguousarray(0.9 * stacks[p][0]) for p in range(3)}
-    with ProjectionFarm(ref, Nw, ms, devices=[None, None], model=("oracle.cpu_model", "port.UMPAModelDF")) as farm:
+    with ProjectionFarm(ref, Nw, ms, devices=[None, None], worker=farm_cpu_worker.run) as farm:
         got = dict(farm.map(sams.items(), num_threads=1))
     assert sorted(got) == [0, 1, 2]
     for p in range(3):
@@ -171,7 +197,7 @@ def test_projection_farm_on_cpu_workers():
     ref_nums = [0, 9]
     raws = {p: np.rint(stacks[p % 3][0] * flats[0 if p < 5 else 1] + dark).astype(np.uint16) for p in (1, 4, 5, 8)}
     with ProjectionFarm(refs, Nw, ms, devices=[None], flats=flats, dark=dark, ref_nums=ref_nums, raw_dtype=np.uint16,
-                        model=("oracle.cpu_model", "port.UMPAModelDF")) as farm:
+                        worker=farm_cpu_worker.run) as farm:
         got = dict(farm.map(raws.items(), num_threads=1))
     for p, raw in raws.items():
         r = 0 if p < 5 else 1
@@ -350,18 +376,15 @@ def test_bench_sharded_leg_rehearsal(tmp_path, gather):
     assert g["parity"].startswith("bit-identical") and g["boundaries"][0]["ranks"] == [0, 1] and g["boundaries"][0]["pixels"] == 16 * 492
 
 
-@pytest.mark.gpu
-def test_projection_farm_two_workers_on_one_gpu(port_ns):
-    """ProjectionFarm(devices=[0, 0]): two worker processes (each its own StreamingMatcher) share the one GPU of the test
-    box -- the multi-device farm of BASELINE config C5 in every respect but the second card -- against the CPU oracle."""
+def _farm_on(devices, port_ns):
     from umpa_amd.farm import ProjectionFarm
     from umpa_amd.synth import make_stack
     Nw, ms, K, n = 3, 4, 4, 160
     sam0, ref, _ = make_stack(n, n + 24, K, ms, df=True, seed=60, amplitude=1.0)
     sams = {p: np.ascontiguousarray(np.roll(sam0, p % 2, axis=2)) for p in range(5)}    # two different sample stacks in turn
-    with ProjectionFarm(ref, Nw, ms, devices=[0, 0]) as farm:
+    with ProjectionFarm(ref, Nw, ms, devices=devices) as farm:
         res = dict(farm.map(sams.items()))
-        assert len(farm._workers) == 2
+        assert len(farm._workers) == len(devices)
     assert sorted(res) == list(range(5))
     for p in range(5):
         o = port_ns.UMPAModelDF(sams[p], ref, window_size=Nw, max_shift=ms)
@@ -373,3 +396,39 @@ def test_projection_farm_two_workers_on_one_gpu(port_ns):
             np.testing.assert_allclose(res[p][k][ok], want[k][ok], rtol=1e-5)
         close = np.abs(res[p]["dx"] - want["dx"]) <= 1e-5 * np.maximum(1.0, np.abs(want["dx"]))
         assert (~close & ok).sum() <= max(2, int(0.002 * ok.sum()))      # (the farm's maps carry no debug arrays to classify with)
+
+
+@pytest.mark.gpu
+def test_projection_farm_two_workers_on_one_gpu(port_ns):
+    """ProjectionFarm(devices=[0, 0]): two worker processes (each its own StreamingMatcher) share the one GPU of the test
+    box -- the multi-device farm of BASELINE config C5 in every respect but the second card -- against the CPU oracle."""
+    _farm_on([0, 0], port_ns)
+
+
+@pytest.mark.gpu
+def test_projection_farm_on_two_devices(port_ns):
+    """ProjectionFarm(devices=[0, 1]): one worker process per GPU (umpa_multi.py:261-270's Pool of workers); needs two
+    visible GPUs (the driver's 8-GPU node)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-device farm needs two")
+    _farm_on([0, 1], port_ns)
+
+
+def test_watchdog_ends_a_wedged_rank():
+    """sharding.Watchdog: a phase that overruns its deadline ends the process with a non-zero exit code (a wedged rank must
+    end the job); a phase that finishes in time does not; run in a child process, as bench.py uses it."""
+    import subprocess
+    prog = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from umpa_amd.sharding import Watchdog\n"
+            "wd = Watchdog(rank=5)\n"
+            "with wd.phase('quick', 5.0): time.sleep(0.05)\n"
+            "print('quick phase done', flush=True)\n"
+            "with wd.phase('halo exchange', 0.4): time.sleep(30)\n"
+            "print('not reached')\n") % REPO
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 3, (out.returncode, out.stdout, out.stderr)
+    assert "quick phase done" in out.stdout and "not reached" not in out.stdout
+    assert "rank 5" in out.stderr and "halo exchange" in out.stderr
+    assert time.time() - t0 < 20

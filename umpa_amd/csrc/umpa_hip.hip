@@ -377,15 +377,22 @@ bool tiled_applicable(const umpa_hip_model* m, const RegionArgs& A, bool forced 
     if (m->has_mask && !masked_supported(m->Nw)) return false;        // corr_masked + replay_cost (umpa_masked.h)
     for (int k = 0; k < m->Na; k++)
         if (m->dims[2 * k] != m->dims[0] || m->dims[2 * k + 1] != m->dims[1]) return false;
-    // corr_volume / corr_masked address a frame with 32-bit byte offsets (LDS-DMA source = base + per-lane offset)
-    if ((size_t)m->dims[0] * m->dims[1] * sizeof(double) >= ((size_t)1 << 32)) return false;
-    if (m->has_mask && m->kind == UMPA_HIP_KIND_DF) {                 // corr_masked stages the means from 16-byte pair planes of the IMAGE
+    // corr_volume / corr_masked address a frame with 32-bit byte offsets in IMAGE coordinates at the frames' pitch (LDS-DMA
+    // source = (frame - its position) + per-lane offset, the offset up to the image's last row: ADVICE round 3)
+    {
         size_t Himg = 0, Wimg = 0;
         for (int k = 0; k < m->Na; k++) {
             Himg = std::max(Himg, (size_t)m->pos[2 * k] + m->dims[2 * k]); Wimg = std::max(Wimg, (size_t)m->pos[2 * k + 1] + m->dims[2 * k + 1]);
         }
-        if (Himg * Wimg * 16 >= ((size_t)1 << 32)) return false;
+        if ((Himg + 1) * (size_t)m->dims[1] * sizeof(double) >= ((size_t)1 << 32)) return false;
+        // corr_masked stages the means from 16-byte pair planes of the IMAGE
+        if (m->has_mask && m->kind == UMPA_HIP_KIND_DF && Himg * Wimg * 16 >= ((size_t)1 << 32)) return false;
     }
+    // One frame, 3x3 windows and masks: a window with as many valid pixels as the model has parameters is fitted EXACTLY,
+    // every cost there is rounding noise around zero and the walk follows the noise -- i.e. the order of the sums.  The
+    // general kernel sums in the reference's order (its walks are the oracle's, test_exact_fit_windows_follow_the_reference_order);
+    // the table-based path does not.
+    if (m->has_mask && m->Na * (2 * m->Nw + 1) * (2 * m->Nw + 1) <= 9 && !forced) return false;
     // stepped regions: the tiled kernels still compute the dense grid, the direct kernel only the requested pixels at
     // about 20 costs each.  Measured on 2048^2 x 10 frames, Nw 5, max_shift 5 (tools/step_rate.py): step 3: 3.5 vs 9.8 ms,
     // 4: 2.5 vs 7.6, 5: 2.4 vs 6.8, 6: 2.4 vs 5.0 -- the dense grid wins up to about 64 dense pixels per requested
@@ -590,8 +597,7 @@ int run_stepping_cells(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g
                               ((int)S.size() == K || known || (int)m->sub_lists.size() < UMPA_SUB_SLOTS);
             if (!tile) { if (int rc = run_block(m, A, g, r0, r1, c0, c1, false, flags, s)) return rc; continue; }
             if ((int)S.size() == K) { if (int rc = run_block(m, A, g, r0, r1, c0, c1, true, flags, s)) return rc; continue; }   // every frame
-            // this subset's descriptor list (a device slot per subset, uploaded when the frames' addresses have changed --
-            // from pageable memory: the copy has left the host buffer when the call returns) and its box
+            // this subset's descriptor list (a device slot per subset, uploaded when the frames' addresses have changed) and its box
             std::vector<FrameDesc> h(S.size());
             FrameSubset sub;
             sub.n = (int)S.size();
@@ -609,8 +615,8 @@ int run_stepping_cells(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g
             if (!known) L.slot = (int)m->sub_lists.size() - 1;
             sub.frames = m->d_sub + (size_t)L.slot * K;
             if (L.host.size() != h.size() || memcmp(L.host.data(), h.data(), h.size() * sizeof(FrameDesc)) != 0) {
-                HIP_TRY(hipMemcpyAsync((void*)sub.frames, h.data(), h.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
-                L.host = h;
+                L.host = h;                                          // the copy's source outlives the enqueue: the map's own storage
+                HIP_TRY(hipMemcpyAsync((void*)sub.frames, L.host.data(), L.host.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
             }
             if (int rc = run_block(m, A, g, r0, r1, c0, c1, true, flags, s, &sub)) return rc;
         }

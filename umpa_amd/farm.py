@@ -104,27 +104,40 @@ class StreamingMatcher:
         from collections import deque
         match_kw.setdefault("quiet", True)
         it = iter(items)
-        cur = next(it, None)
-        cur_ref = self._stage(*cur) if cur is not None else None
         pending = deque()
-        while cur is not None or pending:
-            if cur is not None:
-                if cur_ref != self._refnum:                         # a reference switch needs an idle model: hand out what is in flight
-                    while pending:
-                        pid, res = pending.popleft()
-                        self.model.wait()
-                        yield pid, res
-                self._switch_reference(cur_ref)
-                self.model._out_alloc = self.out_alloc
-                res = self.model.match_async(**match_kw)            # adopts the staged stack, enqueues kernels + downloads
-                pending.append((cur[0], res))
-                nxt = next(it, None)
-                nxt_ref = self._stage(*nxt) if nxt is not None else None   # upload the next one while this one is being matched
-                cur, cur_ref = nxt, nxt_ref
-            if len(pending) == 2 or cur is None:
-                pid, res = pending.popleft()
-                self.model.wait()                                   # the OLDEST match in flight
-                yield pid, res
+        # The library keeps a FIFO of asynchronous matches and `wait` returns the OLDEST one.  If the consumer abandons
+        # this generator (break, close), or staging / a match raises mid-series, the matches still in flight are waited for
+        # here: a later run() on the same matcher must not pair its waits with this series' matches.
+        try:
+            cur = next(it, None)
+            cur_ref = self._stage(*cur) if cur is not None else None
+            while cur is not None or pending:
+                if cur is not None:
+                    if cur_ref != self._refnum:                     # a reference switch needs an idle model: hand out what is in flight
+                        while pending:
+                            pid, res = pending[0]
+                            self.model.wait()
+                            pending.popleft()
+                            yield pid, res
+                    self._switch_reference(cur_ref)
+                    self.model._out_alloc = self.out_alloc
+                    res = self.model.match_async(**match_kw)        # adopts the staged stack, enqueues kernels + downloads
+                    pending.append((cur[0], res))
+                    nxt = next(it, None)
+                    nxt_ref = self._stage(*nxt) if nxt is not None else None   # upload the next one while this one is being matched
+                    cur, cur_ref = nxt, nxt_ref
+                if len(pending) == 2 or cur is None:
+                    pid, res = pending[0]
+                    self.model.wait()                               # the OLDEST match in flight
+                    pending.popleft()
+                    yield pid, res
+        finally:
+            while pending:                                          # nothing of this series stays in the library's queue
+                pending.popleft()
+                try:
+                    self.model.wait()
+                except Exception:
+                    pass
 
 
 # ------------------------------------------------------------------------------------------------
@@ -167,138 +180,110 @@ def _result_layout(N0, N1, df):
     return [("values", (nparam, N0, N1), np.float64), ("err", (N0, N1), np.int32)]
 
 
-def _farm_worker(device, cfg, tasks, results, in_name, out_name):
+def _worker_main(body, device, cfg, tasks, results, in_name, out_name):
+    """What every worker process runs: ``body`` (the GPU worker below, or a stand-in a caller injected with
+    ``ProjectionFarm(worker=...)``) inside the farm's error protocol -- an exception becomes an "error" message, the process
+    always says "exit"."""
     try:
-        if device is not None:
-            os.environ["UMPA_HIP_DEVICE"] = str(device)
-        if cfg["model"] is not None:                                # the CPU checker stands in for the GPU in the CPU tests
-            return _cpu_worker(cfg, tasks, results, in_name, out_name)
-        import ctypes
-        from . import _lib
-        lib = _lib.hip()
-        sm = StreamingMatcher(cfg["refs"], cfg["window_size"], cfg["max_shift"], df=cfg["df"], device=device or 0,
-                              flats=cfg["flats"], dark=cfg["dark"], ref_nums=cfg["ref_nums"])
-        slots_in = _Slots(None, cfg["depth_in"], cfg["in_bytes"], name=in_name)
-        slots_out = _Slots(None, cfg["depth_out"], cfg["out_bytes"], name=out_name)
-        # page-lock both rings once: uploads and downloads then run as DMA at link rate, straight from / into the
-        # memory the parent process sees
-        base_in = ctypes.addressof(ctypes.c_char.from_buffer(slots_in.shm.buf))
-        base_out = ctypes.addressof(ctypes.c_char.from_buffer(slots_out.shm.buf))
-        lib.check(lib.host_register(base_in, slots_in.count * slots_in.nbytes), "host_register")
-        lib.check(lib.host_register(base_out, slots_out.count * slots_out.nbytes), "host_register")
-        shape, dtype = (sm.K, sm.H, sm.W), np.dtype(cfg["raw_dtype"])
-        state = {"slot": 0, "off": 0}
-
-        def out_alloc(shp, dt, zero=False):                         # model.match's result arrays live in the result slot
-            a, state["off"] = slots_out.view(state["slot"], shp, dt, state["off"])
-            if zero:
-                a[...] = 0
-            return a
-
-        def stage(task):
-            seq, pid, q_in, q_out, kw = task
-            raw, _ = slots_in.view(q_in, shape, dtype)
-            return sm._stage(pid, raw)
-
-        def stage_or_report(task):
-            """(reference number, None) of a staged task, or (None, message) when its upload failed"""
-            try:
-                return stage(task), None
-            except Exception as e:                                  # this projection only: the worker goes on
-                import traceback
-                return None, repr(e) + "\n" + traceback.format_exc()
-
-        cur = tasks.get()
-        cur_ref, cur_err = stage_or_report(cur) if cur is not None else (None, None)
-        while cur is not None:
-            seq, pid, q_in, q_out, kw = cur
-            matched = False
-            if cur_err is None:
-                try:
-                    sm._switch_reference(cur_ref)
-                    state["slot"], state["off"] = q_out, 0
-                    sm.model._out_alloc = out_alloc
-                    kw = dict(kw)
-                    kw.setdefault("quiet", True)
-                    sm.model.match_async(**kw)                      # adopts the staged stack; kernels + downloads enqueued
-                    matched = True
-                except Exception as e:
-                    import traceback
-                    cur_err = repr(e) + "\n" + traceback.format_exc()
-            nxt, nxt_ref, nxt_err, have_next = None, None, None, False
-            try:
-                nxt = tasks.get_nowait()                            # upload the next projection while this one is matched
-                have_next = True
-                if nxt is not None:
-                    nxt_ref, nxt_err = stage_or_report(nxt)
-            except _queue.Empty:
-                pass
-            if matched:
-                try:
-                    sm.model.wait()
-                except Exception as e:
-                    import traceback
-                    cur_err = repr(e) + "\n" + traceback.format_exc()
-            results.put(("done", seq, q_in, q_out, cur_err))
-            if not have_next:
-                nxt = tasks.get()
-                nxt_ref, nxt_err = stage_or_report(nxt) if nxt is not None else (None, None)
-            cur, cur_ref, cur_err = nxt, nxt_ref, nxt_err
-    except Exception as e:                                          # a worker that cannot run must not hang the farm
+        body(device, cfg, tasks, results, in_name, out_name)
+    except BaseException as e:                                      # noqa: BLE001 -- the parent must hear about everything
         import traceback
         results.put(("error", None, None, None, repr(e) + "\n" + traceback.format_exc()))
     finally:
         results.put(("exit", device, None, None, None))
 
 
-def _cpu_worker(cfg, tasks, results, in_name, out_name):
-    """The same protocol with the CPU checker (tests on machines without a GPU)."""
-    import importlib
-    mod_name, cls_name = cfg["model"]
-    ns = importlib.import_module(mod_name)
-    for part in cls_name.split("."):
-        ns = getattr(ns, part)
+def _farm_worker(device, cfg, tasks, results, in_name, out_name):
+    """The GPU worker: one StreamingMatcher on `device`, projections and maps through the shared-memory slots."""
+    if device is not None:
+        os.environ["UMPA_HIP_DEVICE"] = str(device)
+    import ctypes
+    from . import _lib
+    lib = _lib.hip()
+    sm = StreamingMatcher(cfg["refs"], cfg["window_size"], cfg["max_shift"], df=cfg["df"], device=device or 0,
+                          flats=cfg["flats"], dark=cfg["dark"], ref_nums=cfg["ref_nums"])
     slots_in = _Slots(None, cfg["depth_in"], cfg["in_bytes"], name=in_name)
     slots_out = _Slots(None, cfg["depth_out"], cfg["out_bytes"], name=out_name)
-    refs = np.asarray(cfg["refs"], dtype=np.float64)
-    if refs.ndim == 3:
-        refs = refs[None]
-    K, H, W = refs.shape[1:]
-    while True:
-        item = tasks.get()
-        if item is None:
-            return
-        seq, pid, q_in, q_out, match_kw = item
-        raw, _ = slots_in.view(q_in, (K, H, W), np.dtype(cfg["raw_dtype"]))
-        refnum = nearest_reference(pid, cfg["ref_nums"]) if cfg["ref_nums"] is not None else 0
-        sam = raw.astype(np.float64)
-        if cfg["dark"] is not None:
-            sam = sam - np.asarray(cfg["dark"], dtype=np.float64)
-        if cfg["flats"] is not None:
-            fl = np.asarray(cfg["flats"], dtype=np.float64)
-            sam = sam / (fl[refnum] if fl.ndim == 4 else fl)
-        m = ns(np.ascontiguousarray(sam), refs[refnum], window_size=cfg["window_size"], max_shift=cfg["max_shift"])
-        m.debug = False
-        res = m.match(quiet=True, **match_kw)
-        N0, N1 = res["err"].shape
-        off = 0
-        keys = RESULT_KEYS_DF if cfg["df"] else tuple(k for k in RESULT_KEYS_DF if k != "df")
-        vals, off = slots_out.view(q_out, (len(keys) - 1, N0, N1), np.float64, off)
-        for n, k in enumerate(k for k in keys if k != "err"):
-            vals[n] = res[k]
-        e, off = slots_out.view(q_out, (N0, N1), np.int32, off)
-        e[...] = res["err"]
-        results.put(("done", seq, q_in, q_out, None))
+    # page-lock both rings once: uploads and downloads then run as DMA at link rate, straight from / into the
+    # memory the parent process sees
+    base_in = ctypes.addressof(ctypes.c_char.from_buffer(slots_in.shm.buf))
+    base_out = ctypes.addressof(ctypes.c_char.from_buffer(slots_out.shm.buf))
+    lib.check(lib.host_register(base_in, slots_in.count * slots_in.nbytes), "host_register")
+    lib.check(lib.host_register(base_out, slots_out.count * slots_out.nbytes), "host_register")
+    shape, dtype = (sm.K, sm.H, sm.W), np.dtype(cfg["raw_dtype"])
+    state = {"slot": 0, "off": 0}
+
+    def out_alloc(shp, dt, zero=False):                         # model.match's result arrays live in the result slot
+        a, state["off"] = slots_out.view(state["slot"], shp, dt, state["off"])
+        if zero:
+            a[...] = 0
+        return a
+
+    def stage(task):
+        seq, pid, q_in, q_out, kw = task
+        raw, _ = slots_in.view(q_in, shape, dtype)
+        return sm._stage(pid, raw)
+
+    def stage_or_report(task):
+        """(reference number, None) of a staged task, or (None, message) when its upload failed"""
+        try:
+            return stage(task), None
+        except Exception as e:                                  # this projection only: the worker goes on
+            import traceback
+            return None, repr(e) + "\n" + traceback.format_exc()
+
+    cur = tasks.get()
+    cur_ref, cur_err = stage_or_report(cur) if cur is not None else (None, None)
+    while cur is not None:
+        seq, pid, q_in, q_out, kw = cur
+        matched = False
+        if cur_err is None:
+            try:
+                sm._switch_reference(cur_ref)
+                state["slot"], state["off"] = q_out, 0
+                sm.model._out_alloc = out_alloc
+                kw = dict(kw)
+                kw.setdefault("quiet", True)
+                sm.model.match_async(**kw)                      # adopts the staged stack; kernels + downloads enqueued
+                matched = True
+            except Exception as e:
+                import traceback
+                cur_err = repr(e) + "\n" + traceback.format_exc()
+        nxt, nxt_ref, nxt_err, have_next = None, None, None, False
+        try:
+            nxt = tasks.get_nowait()                            # upload the next projection while this one is matched
+            have_next = True
+            if nxt is not None:
+                nxt_ref, nxt_err = stage_or_report(nxt)
+        except _queue.Empty:
+            pass
+        if matched:
+            try:
+                sm.model.wait()
+            except Exception as e:
+                import traceback
+                cur_err = repr(e) + "\n" + traceback.format_exc()
+        results.put(("done", seq, q_in, q_out, cur_err))
+        if not have_next:
+            nxt = tasks.get()
+            nxt_ref, nxt_err = stage_or_report(nxt) if nxt is not None else (None, None)
+        cur, cur_ref, cur_err = nxt, nxt_ref, nxt_err
+
+
+class ProjectionFailed(RuntimeError):
+    """One projection failed in its worker (the farm itself is intact)."""
 
 
 class ProjectionFarm:
     def __init__(self, ref_stack, window_size, max_shift=4, df=True, devices=None, flats=None, dark=None, ref_nums=None,
-                 raw_dtype=np.float64, depth=2, model=(None, None), save_pattern=None):
+                 raw_dtype=np.float64, depth=2, worker=None, save_pattern=None):
         """``devices``: HIP device indices, one worker process each (default: all visible devices).
         ``flats`` / ``dark`` / ``ref_nums``: the flat-field data of ``umpa_multi.py:133-145`` (optional).
         ``raw_dtype``: dtype of the projections as submitted (float64, float32 or uint16).
         ``depth``: shared-memory slots per worker for inputs and for results.
-        ``model``: (module, class path) of a CPU model class -- the CPU tests point it at the checker.
+        ``worker``: a picklable callable ``(device, cfg, tasks, results, in_name, out_name)`` to run in the worker processes
+        instead of the GPU worker (same queue / slot protocol).  The package itself has no other worker; the CPU tests
+        inject one of their own (tests/farm_cpu_worker.py) to exercise the farm's plumbing on machines without a GPU.
         ``save_pattern``: e.g. ``"/data/out/umpa_%04d.npz"``: results are also written there (``umpa_multi.py:185``)."""
         if devices is None:
             from . import _lib
@@ -315,18 +300,17 @@ class ProjectionFarm:
         in_bytes = (self.K * self.H * self.W * self.raw_dtype.itemsize + 4095) & ~4095
         out_bytes = sum(((int(np.prod(s)) * np.dtype(d).itemsize + 63) & ~63) for _, s, d in _result_layout(self.N0, self.N1, df))
         out_bytes = (out_bytes + 4095) & ~4095
-        mod, cls = model
         cfg = dict(refs=refs, window_size=int(window_size), max_shift=int(max_shift), df=self.df, flats=flats, dark=dark,
                    ref_nums=ref_nums, raw_dtype=self.raw_dtype.str, depth_in=depth, depth_out=depth, in_bytes=in_bytes,
-                   out_bytes=out_bytes, model=(mod, cls or ("UMPAModelDF" if df else "UMPAModelNoDF")) if mod else None)
+                   out_bytes=out_bytes)
         self._workers = []
         self._results = self._ctx.Queue()
         for d in devices:
             w = dict(device=d, tasks=self._ctx.Queue(), slots_in=_Slots(self._ctx, depth, in_bytes),
                      slots_out=_Slots(self._ctx, depth, out_bytes), free_in=list(range(depth)), free_out=list(range(depth)),
                      inflight=0)
-            w["proc"] = self._ctx.Process(target=_farm_worker, daemon=True,
-                                          args=(d, cfg, w["tasks"], self._results, w["slots_in"].name, w["slots_out"].name))
+            w["proc"] = self._ctx.Process(target=_worker_main, daemon=True,
+                                          args=(worker or _farm_worker, d, cfg, w["tasks"], self._results, w["slots_in"].name, w["slots_out"].name))
             w["proc"].start()
             self._workers.append(w)
         self._by_seq = {}                                           # in flight: internal sequence number -> (worker, caller's id)
@@ -390,7 +374,7 @@ class ProjectionFarm:
             if err is not None:                                     # this projection failed in its worker; the farm goes on
                 w["free_out"].append(q_out)
                 w["inflight"] -= 1
-                raise RuntimeError("projection %r failed in the farm worker for device %r: %s" % (pid, w["device"], err))
+                raise ProjectionFailed("projection %r failed in the farm worker for device %r: %s" % (pid, w["device"], err))
             off = 0
             res = {}
             for key, shape, dtype in _result_layout(self.N0, self.N1, self.df):
@@ -428,6 +412,7 @@ class ProjectionFarm:
         it = iter(projections)
         exhausted = False
         inflight = 0
+        failed = None
         while not exhausted or inflight:
             while not exhausted:
                 got = self.input_buffer()
@@ -450,13 +435,24 @@ class ProjectionFarm:
                 self._raise_if_dead(timeout)
                 continue
             if inflight:
-                pid, res, release = self._collect(timeout)
+                try:
+                    pid, res, release = self._collect(timeout)
+                except ProjectionFailed as e:
+                    # this projection is lost, the ones still in flight are not: nothing new is submitted, what is in
+                    # flight is collected (and handed out), then the first failure is raised -- a later map() on this farm
+                    # finds no stale results in the queue
+                    failed = failed or e
+                    inflight -= 1
+                    exhausted = True
+                    continue
                 out = {k: np.array(v) for k, v in res.items()}
                 if self.save_pattern:
                     np.savez(self.save_pattern % pid, **out)
                 release()
                 inflight -= 1
                 yield pid, out
+        if failed is not None:
+            raise failed
 
     def close(self):
         for w in self._workers:

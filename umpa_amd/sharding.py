@@ -186,19 +186,23 @@ class RowShardedStack:
 def exchange_halos(stacks, group=None):
     """Fill the halo rows of every ``RowShardedStack`` in ``stacks`` from the neighbour ranks: all sends and
     receives of all stacks go into ONE ``batch_isend_irecv`` group (``ncclSend``/``ncclRecv`` under RCCL, one
-    xGMI link per neighbour and direction).  With the gloo backend the rows are staged through the host."""
+    xGMI link per neighbour and direction).  Under RCCL every transfer is one frame's rows -- a contiguous view of the
+    persistent buffer on both sides: sent from where the producer wrote them, received straight into the rows the model
+    borrows, no staging tensor and no copy.  With the gloo backend the rows are staged through the host."""
     import torch
     import torch.distributed as dist
     via_host = dist.get_backend(group) != "nccl"
     ops, landing = [], []
     for st in stacks:
         for peer, kind, r0, r1 in st.halo_plan():
-            view = st.rows(r0, r1)
-            if kind == "send":
-                t = view.contiguous()
-                ops.append(dist.P2POp(dist.isend, t.cpu() if via_host else t, peer, group))
+            view = st.rows(r0, r1)                                  # [K, rows, W]: contiguous per frame
+            if not via_host:
+                for k in range(st.K):
+                    ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, view[k], peer, group))
+            elif kind == "send":
+                ops.append(dist.P2POp(dist.isend, view.contiguous().cpu(), peer, group))
             else:
-                t = torch.empty(view.shape, dtype=view.dtype, device="cpu" if via_host else view.device)
+                t = torch.empty(view.shape, dtype=view.dtype, device="cpu")
                 ops.append(dist.P2POp(dist.irecv, t, peer, group))
                 landing.append((view, t))
     if ops:
@@ -206,6 +210,76 @@ def exchange_halos(stacks, group=None):
             req.wait()
     for view, t in landing:
         view.copy_(t)
+
+
+class Watchdog:
+    """A rank that hangs in a collective (a dead peer, a wedged link) must end the job, not hold it: ``with
+    wd.phase("halo", 30):`` arms a deadline for the block; if it passes, a daemon thread reports which rank sat in which
+    phase for how long and ends THIS process with a non-zero exit code (``os._exit``: a fresh exit, no interpreter
+    shutdown that could block on the GPU runtime, and never an exec of a process that has touched the GPU) -- the
+    launcher (torch.distributed.run) then tears the other ranks down.  Process-group construction has its own
+    ``timeout=`` (bench.py passes it to ``init_process_group``)."""
+
+    def __init__(self, rank=0, exit_code=3, stream=None):
+        import threading
+        self.rank, self.exit_code = int(rank), int(exit_code)
+        self._stream = stream
+        self._lock = threading.Lock()
+        self._armed = None                                          # (name, deadline, seconds)
+        self._stop = False
+        self.fired = None
+        self._thread = threading.Thread(target=self._run, name="umpa-watchdog", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        import sys
+        import time
+        while not self._stop:
+            time.sleep(0.2)
+            with self._lock:
+                armed = self._armed
+            if armed and time.monotonic() > armed[1]:
+                msg = "[umpa watchdog] rank %d: phase %r still running after %.0f s -- ending this process (exit code %d)\n" % (
+                    self.rank, armed[0], armed[2], self.exit_code)
+                (self._stream or sys.stderr).write(msg)
+                (self._stream or sys.stderr).flush()
+                self.fired = armed[0]
+                self._exit(self.exit_code)
+                return
+
+    def _exit(self, code):                                          # (a seam for the tests)
+        import os
+        os._exit(code)
+
+    def phase(self, name, seconds):
+        import contextlib
+        import time
+
+        @contextlib.contextmanager
+        def cm():
+            with self._lock:
+                self._armed = (name, time.monotonic() + float(seconds), float(seconds))
+            try:
+                yield
+            finally:
+                with self._lock:
+                    self._armed = None
+        return cm()
+
+    def close(self):
+        self._stop = True
+
+
+def describe_device(index):
+    """'<name> uuid=<...> pci=<bus id>' of HIP device ``index`` (printed per rank by bench.py: which GPUs a run used)."""
+    import torch
+    p = torch.cuda.get_device_properties(index)
+    parts = [p.name]
+    for key in ("uuid", "pci_bus_id", "pci_device_id", "gcnArchName"):
+        v = getattr(p, key, None)
+        if v is not None:
+            parts.append("%s=%s" % (key, v))
+    return " ".join(str(x) for x in parts)
 
 
 def gather_slabs(local, n_rows, dst=0, group=None, out=None):
