@@ -308,6 +308,7 @@ static int minimise(const oracle_model *m, int i, int j, const double *kern,
 {
     int ci = (int)round(uv[0]), cj = (int)round(uv[1]);         /* :258-259 */
     int n = 0, st, axis = 0, found[2] = {0, 0};
+    int moves = 0, n_at_move = 0;                               /* centre moves since the last cost call, see MOVE_CAP below */
     fit_t kept;
     for (int q = 0; q < 25; q++) memo[q] = -1.0;                /* :252 */
 
@@ -384,6 +385,12 @@ static int minimise(const oracle_model *m, int i, int j, const double *kern,
         if (axis) ci += dir; else cj += dir;
         memo_shift(memo, axis, dir);
         found[1 - axis] = 0;
+        /* NOT in the reference, which never returns from this: with a NaN cost in the neighbourhood (a masked window without
+           a valid pixel pair) the centre can step between two memoised cells for ever, no call is made and the call cap is
+           never reached.  64 moves in a row without a cost call end the walk like the cap does (umpa_walk.h: UMPA_MOVE_CAP,
+           the same rule); walks on finite costs never get there. */
+        if (n != n_at_move) { n_at_move = n; moves = 0; }
+        if (++moves > 64) return st & ~ST_OK;
     }
     return st & ~ST_OK;                                         /* :477 */
 }

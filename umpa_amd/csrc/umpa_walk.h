@@ -18,6 +18,12 @@
 
 #define UMPA_CALL_CAP 500          // Optim.cpp:14 (the default of ModelDev::call_cap)
 #define UMPA_TIE      1e-8         // Optim.cpp:243
+// The reference's loop (Optim.cpp:267-474) only tests its call cap, and moves between memoised cells cost no call: with a
+// NaN cost in the neighbourhood (a masked window without a single valid pixel pair: 0/0) the centre can step back and forth
+// between two known cells for ever -- the reference hangs there.  A GPU kernel must not: this many moves in a row without a
+// cost call end the walk like the call cap does (status not ok).  oracle/umpa_oracle.c carries the same rule; no walk on
+// finite costs comes near it (a 5x5 memo holds at most four known cells in a row).
+#define UMPA_MOVE_CAP 64
 
 namespace umpa {
 
@@ -229,6 +235,7 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
     // finishes its iteration (the other probe, then the move or the gather); `goto start` skips the test as well.
     bool cap_test = w.phase == PH_CENTRE;
     bool scan = false;
+    int moves = 0;                                              // centre moves since the last cost call (UMPA_MOVE_CAP)
     if (w.phase == PH_GATHER) {                                 // Optim.cpp:353-378
         const int rr = w.ip + (w.g >> 2), cc = w.jp + (w.g & 3);   // the `a` entry is this cell of the neighbourhood
         memo[walk_slot(w, rr, cc)] = val;
@@ -326,6 +333,11 @@ __device__ inline void walk_feed(Walk& w, Memo memo, int st, double val, Fit fit
                 w.found1 = 0;
             }
             w.c0 = up ? dhi : dlo;                              // the new centre is the neighbour stepped onto
+            if (++moves > UMPA_MOVE_CAP) {                      // (never on finite costs; see UMPA_MOVE_CAP)
+                w.status = st & ~UMPA_ST_OK;
+                w.phase = PH_DONE;
+                return;
+            }
         }
     }
     // fill the 4x4 neighbourhood, asking for what is missing in the reference's order (Optim.cpp:353-362)
