@@ -122,7 +122,7 @@ def roofline(kernels, steps, abytes, config, useful=None, ms_per_step=None):
                kernels_ms={k: round(v[0] * v[1] / steps, 4) for k, v in kernels.items()}, hbm=hbm)
     if fma > 0:
         tf_exec = 2.0 * fma / (dur_ms * 1e-3) / 1e12
-        have_useful = bool(useful) and dom == "corr_volume"
+        have_useful = bool(useful) and dom in ("corr_volume", "corr_march")
         tf = 2.0 * useful / (dur_ms * 1e-3) / 1e12 if have_useful else tf_exec
         out.update(bound="fp64_fma", achieved=round(tf, 3), peak=FP64_PEAK_TF, unit="TFLOP/s", frac=round(tf / FP64_PEAK_TF, 5),
                    frac_executed=round(tf_exec / FP64_PEAK_TF, 5),

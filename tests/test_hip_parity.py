@@ -6,6 +6,8 @@ seeded inputs.  Bar: err / Ncalls / integer minimum bit-exact, float maps <= 1e-
 """
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -585,3 +587,57 @@ def test_masks_and_sample_stepping_together(hip_ns, port_ns, df):
     got, want = g.match(ROI=roi, quiet=True), o.match(ROI=roi, quiet=True)
     assert g._lib.last_path(g._handle) == 2
     assert_parity(got, want, ms, "masks + stepping ROI %s" % name)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(H=210, W=333, K=5, Nw=6, ms=5, df=True, assign="sam", mk=dict()),
+    dict(H=180, W=260, K=3, Nw=7, ms=8, df=True, assign="ref", mk=dict(step=2, dxdy=(1, -1))),
+    dict(H=200, W=215, K=4, Nw=7, ms=3, df=False, assign="sam", mk=dict()),                      # odd region width, few shifts
+    dict(H=400, W=190, K=7, Nw=6, ms=9, df=True, assign="sam", mk=dict(), table_mb=64),           # 17 x 17 shifts, several row chunks
+    dict(H=230, W=250, K=4, Nw=6, ms=4, df=True, assign="sam", mk=dict(), pos=[(0, 0), (0, 11), (9, 0), (9, 11)]),   # sample stepping
+])
+def test_wide_windows_take_the_marching_table_kernel(hip_ns, port_ns, monkeypatch, cfg):
+    """Windows of 13 and 15 pixels: the shift table comes from corr_march (umpa_march.h: column strips marched down the rows,
+    row filter as a register ring, column filter by DPP shifts, strip-blocked table) instead of corr_volume.  Against the CPU
+    oracle to the full bar, and against corr_volume (UMPA_HIP_MARCH=0): the same walk on every pixel -- the two kernels sum in
+    different orders, so the maps agree to rounding, not bit for bit."""
+    from umpa_amd.synth import make_stack
+    Nw, ms, K = cfg["Nw"], cfg["ms"], cfg["K"]
+    kw = dict(window_size=Nw, max_shift=ms)
+    if cfg.get("pos"):
+        frames = [make_stack(cfg["H"], cfg["W"], 1, ms, df=cfg["df"], seed=500 + k, amplitude=min(2.0, ms - 1.5), order=1) for k in range(K)]
+        sam = [np.ascontiguousarray(f[0][0]) for f in frames]
+        ref = [np.ascontiguousarray(f[1][0]) for f in frames]
+        kw["pos_list"] = [np.array(p) for p in cfg["pos"]]
+    else:
+        sam, ref, _ = make_stack(cfg["H"], cfg["W"], K, ms, df=cfg["df"], seed=77, amplitude=min(3.0, ms - 1.5), order=1)
+    name = "UMPAModelDF" if cfg["df"] else "UMPAModelNoDF"
+    if cfg.get("table_mb"):
+        monkeypatch.setenv("UMPA_HIP_TABLE_MB", str(cfg["table_mb"]))
+    res = {}
+    for march in ("1", "0"):
+        monkeypatch.setenv("UMPA_HIP_MARCH", march)
+        g = getattr(hip_ns, name)(sam, ref, **kw)
+        g.assign_coordinates = cfg["assign"]
+        g.debug = True
+        g._lib.timing_enable(g._handle, 1)
+        res[march] = g.match(quiet=True, **cfg["mk"])
+        g._lib.timing_enable(g._handle, 0)
+        assert g._lib.last_path(g._handle) in (2, 4)
+        names = set()
+        for q in range(g._lib.timing_collect(g._handle)):
+            nm, tot, cnt = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int()
+            g._lib.timing_read(g._handle, q, ctypes.byref(nm), ctypes.byref(tot), ctypes.byref(cnt))
+            names.add(nm.value.decode())
+        assert ("corr_march" in names) == (march == "1") and ("corr_volume" in names) == (march == "0"), names
+    o = getattr(port_ns, name)(sam, ref, **kw)
+    o.assign_coordinates = cfg["assign"]
+    o.debug = True
+    want = o.match(quiet=True, **cfg["mk"])
+    st = assert_parity(res["1"], want, ms, "march %s" % cfg)
+    assert st["ok"] > 500
+    for k in ("err", "debug_Ncalls"):
+        np.testing.assert_array_equal(res["1"][k], res["0"][k], err_msg=k)
+    ok = res["0"]["err"] == 1
+    np.testing.assert_allclose(res["1"]["T"][ok], res["0"]["T"][ok], rtol=1e-9)
+    np.testing.assert_allclose(res["1"]["debug_d"], res["0"]["debug_d"], rtol=1e-9, atol=1e-14)

@@ -1,4 +1,4 @@
-// Development harness of corr_march (tools/microbench/corr_march.h, an experiment: not part of the library): the kernel alone on random stacks of BASELINE config C2's
+// Development harness of corr_march (umpa_amd/csrc/umpa_march.h): the kernel alone on random stacks of BASELINE config C2's
 // (or C3's) geometry, checked against a plain CPU sum on sampled (pixel, shift) pairs and on whole rows at the region's edges.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I umpa_amd/csrc -I tools/microbench tools/microbench/march_dev.hip -o _exp/march_dev
 //   gpurun_out/march_dev [c2|c3|small] [nbands] [ablate]
@@ -9,7 +9,7 @@
 #include <cmath>
 #include <vector>
 #include <random>
-#include "corr_march.h"
+#include "umpa_march.h"
 
 using namespace umpa;
 
@@ -129,6 +129,7 @@ int main(int argc, char** argv)
     else if (Nw == 5 && NT == 576 && npt <= 2 && LA == 2) best = run<5, 2, 2, 2, 576, 3>(dev, A, sep, lds, grid, reps);
     else if (Nw == 7 && NT == 512 && npt <= 3 && LA == 2) best = run<7, 4, 3, 2, 512, 2>(dev, A, sep, lds, grid, reps);
     else if (Nw == 7 && NT == 768 && npt <= 2 && LA == 2) best = run<7, 4, 2, 2, 768, 3>(dev, A, sep, lds, grid, reps);
+    else if (Nw == 7 && NT == 768 && npt <= 2 && LA == 3) best = run<7, 4, 2, 3, 768, 3>(dev, A, sep, lds, grid, reps);
     else { printf("no instantiation for Nw=%d NT=%d npt=%d\n", Nw, NT, npt); return 1; }
     const double useful = (double)(K + 2 * (2 * Nw + 1)) * UJ * UJ * N0 * N1;
     printf("useful FMA %.3f G -> %.1f TFLOP/s (%.1f %% of 78.6); %.0f Mpx/s for this kernel alone\n", useful * 1e-9, 2 * useful / best * 1e-9,

@@ -126,8 +126,8 @@ struct umpa_hip_model {
 
 namespace {
 
-const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk", "match_staged", "corr_masked", "replay_cost", "blur_tiles"};
-enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4, KN_STAGED = 5, KN_MASKED = 6, KN_REPLAY_COST = 7, KN_BLUR = 8 };
+const char* const KERNEL_NAMES[] = {"match_direct", "coverage", "prep_maps", "corr_volume", "replay_walk", "match_staged", "corr_masked", "replay_cost", "blur_tiles", "corr_march"};
+enum { KN_DIRECT = 0, KN_COVER = 1, KN_PREP = 2, KN_CORR = 3, KN_REPLAY = 4, KN_STAGED = 5, KN_MASKED = 6, KN_REPLAY_COST = 7, KN_BLUR = 8, KN_MARCH = 9 };
 
 hipEvent_t get_event(umpa_hip_model* m)
 {
@@ -458,7 +458,7 @@ StepGeom step_geometry(const umpa_hip_model* m, const RegionArgs& A)
 
 // `sub`: the frames that contribute in this sub-rectangle of a sample-stepping stack (a descriptor list of its own, the box
 // of image rows / columns inside every one of them); NULL = all frames
-struct FrameSubset { const FrameDesc* frames; int n; FrameBox box; };
+struct FrameSubset { const FrameDesc* frames; int n; FrameBox box; const FrameDesc* host; };   // host: the same list in host memory
 
 int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int flags, hipStream_t s,
               int piece_rows, const std::function<void(int, int)>& on_rows, const FrameSubset* sub = nullptr)
@@ -468,11 +468,20 @@ int run_tiled(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g, int fla
     ModelDev dev = m->dev();
     if (sub) { dev.frames = sub->frames; dev.Na = sub->n; m->tiled.ref_maps_ok = false; }      // (Nwt stays the model's frame count)
     const bool reuse = !sub && (flags & UMPA_HIP_F_REUSE_REF_MAPS) != 0;
+    std::vector<FrameDesc> hf;                                        // a host copy of the frame list (corr_march's staging offsets)
+    if (!sub) {
+        hf.resize(m->Na);
+        for (int k = 0; k < m->Na; k++) {
+            memset(&hf[k], 0, sizeof(FrameDesc));
+            hf[k].sam = m->d_sam[k]; hf[k].ref = m->d_ref[k]; hf[k].mask = m->d_mask[k];
+            hf[k].H = m->dims[2 * k]; hf[k].W = m->dims[2 * k + 1]; hf[k].pi = m->pos[2 * k]; hf[k].pj = m->pos[2 * k + 1];
+        }
+    }
     int rc = m->has_mask
         ? tiled_match_masked(m->tiled, dev, m->kind, g.Himg, g.Wimg, sub ? sub->box : g.box, A, s,
                              m->timing ? &tt : nullptr, reuse, m->mask_binary, piece_rows, on_rows)
         : tiled_match(m->tiled, dev, m->kind, g.Himg, g.Wimg, sub ? sub->box : g.box, A, s,
-                      m->timing ? &tt : nullptr, reuse, piece_rows, on_rows);
+                      m->timing ? &tt : nullptr, reuse, piece_rows, on_rows, sub ? sub->host : hf.data());
     if (sub) m->tiled.ref_maps_ok = false;                            // the maps now hold a subset's planes
     if (rc == -3) return fail(UMPA_HIP_E_NOMEM, "tiled path: device scratch allocation failed");
     if (rc != 0) return fail(UMPA_HIP_E_LAUNCH, "tiled path: launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
@@ -614,10 +623,12 @@ int run_stepping_cells(umpa_hip_model* m, const RegionArgs& A, const StepGeom& g
             umpa_hip_model::SubList& L = m->sub_lists[mask];
             if (!known) L.slot = (int)m->sub_lists.size() - 1;
             sub.frames = m->d_sub + (size_t)L.slot * K;
+            sub.host = nullptr;
             if (L.host.size() != h.size() || memcmp(L.host.data(), h.data(), h.size() * sizeof(FrameDesc)) != 0) {
                 L.host = h;                                          // the copy's source outlives the enqueue: the map's own storage
                 HIP_TRY(hipMemcpyAsync((void*)sub.frames, L.host.data(), L.host.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, s), UMPA_HIP_E_DEVICE);
             }
+            sub.host = L.host.data();
             if (int rc = run_block(m, A, g, r0, r1, c0, c1, true, flags, s, &sub)) return rc;
         }
     }

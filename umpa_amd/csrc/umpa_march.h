@@ -1,4 +1,4 @@
-// corr_march.h -- AN EXPERIMENT (round 4), not part of the library: the table of corr_volume,
+// umpa_march.h -- corr_march, the table kernel of the tiled path for wide windows (round 4): the numbers of corr_volume,
 //   t5[u][p] = sum_k W[ s_k(.) r_k(.+u) ](p)                              (Model.cpp:763-772, window = hr (x) hc, model.pyx:691-696)
 // by MARCHING instead of tiling.  A workgroup owns a column strip of the region and a band of its rows and walks down the
 // patch rows of the band one row per step; a pass is NUY consecutive row offsets x every column offset of the search range.

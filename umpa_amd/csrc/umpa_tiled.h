@@ -27,6 +27,7 @@
 #pragma once
 #include "umpa_direct.h"
 #include "umpa_corr.h"
+#include "umpa_march.h"
 #include "umpa_masked.h"
 #include <mutex>
 #include <vector>
@@ -202,6 +203,8 @@ struct ReplayArgs {
     const double* table;      // [(2ms-1)^2][drows][N1d]: the DENSE (unit-step) grid under the requested region
     size_t slot_stride;       // drows * N1d
     int drow0, N1d;           // first dense row held by the table, doubles per table row (the dense row length, padded: CorrArgs::pitch)
+    int strip_w, tw, drows;   // strip_w > 0: the table is corr_march's, blocked by column strips of strip_w dense columns:
+                              // [strip][drows][(2ms-1)^2][tw]; slot_stride = tw
     int row0, rows;           // OUTPUT rows [row0, row0+rows) whose dense rows the table holds
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE_REPLAY): 1 = 18 fixed lookups instead of the walk, 2 = no sub-pixel fit
 };
@@ -415,7 +418,11 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         live = xi < R.row0 + R.rows && xj < A.N1;
     }
     const size_t px = (size_t)xi * A.pitch + xj;                     // in the output arrays
-    const size_t tpx = (size_t)(xi * A.step0 - R.drow0) * R.N1d + (size_t)xj * A.step1;
+    size_t tpx = (size_t)(xi * A.step0 - R.drow0) * R.N1d + (size_t)xj * A.step1;
+    if (R.strip_w > 0) {                                             // corr_march's strip-blocked table (umpa_march.h)
+        const int dc = xj * A.step1, strip = dc / R.strip_w, UJr = 2 * m.ms - 1;
+        tpx = (((size_t)strip * R.drows + (size_t)(xi * A.step0 - R.drow0)) * (size_t)(UJr * UJr)) * R.tw + (size_t)(dc - strip * R.strip_w);
+    }
     if (live && A.cover && gp(A.cover)[px] < A.thr) live = false;
     OdLane L;
     if (live && !od_begin(od, xi * A.step0 - R.drow0, xj * A.step1, L)) live = false;
@@ -520,6 +527,9 @@ struct TiledState {
     int ref_kind = -1, ref_K = 0;
     size_t ref_plane = 0;
     int ref_rect[4] = {0, 0, 0, 0};   // tiles (tx0, tx1, ty0, ty1) of the maps that were computed (PrepRect)
+    // corr_march (umpa_march.h): the frames' 32-bit byte offsets from the two stacks' base addresses, [2][K] on the device
+    unsigned* march_off = nullptr;  int march_off_cap = 0;
+    std::vector<unsigned> march_off_host;
     // on-demand passes (umpa_ondemand.h): device scratch, and page-locked slots the counters of a timed match land in
     void* od_buf = nullptr;   size_t od_cap = 0;
     int* od_host = nullptr;   int od_slot = 0;
@@ -570,6 +580,8 @@ inline void tiled_release(TiledState& st)
     if (st.table) (void)hipFree(st.table);
     if (st.od_buf) (void)hipFree(st.od_buf);
     if (st.od_host) (void)hipHostFree(st.od_host);
+    if (st.march_off) (void)hipFree(st.march_off);
+    st.march_off = nullptr; st.march_off_cap = 0; st.march_off_host.clear();
     st.maps = st.table = nullptr;
     st.od_buf = nullptr; st.od_host = nullptr; st.od_cap = 0;
     st.maps_cap = st.table_cap = 0;
@@ -745,6 +757,131 @@ inline hipError_t launch_corr_nw(int ub, const ModelDev& dev, const CorrArgs& A,
     return launch_corr_shape<NW, 5>(dev, A, sep, s, L);
 }
 
+// ------------------------------------------------------------------------------------------------
+// corr_march (umpa_march.h): the table kernel for wide windows
+// ------------------------------------------------------------------------------------------------
+// rows / columns of the image inside every frame, the frames' common width (tiled_match)
+struct FrameBox { int r0, r1, c0, c1, Wf; int slack; };   // slack: 1 if 8 readable bytes follow every frame row's last column
+
+// corr_volume's tiles carry a halo of 2 Nw rows and columns and restage it for every pass: at Nw = 7, max_shift = 8 (BASELINE
+// config C3) it moves 147 GB from L2 into LDS per match -- which at the rate a CU's vector-memory path sustains IS its
+// 28.9 ms.  corr_march stages 40 GB for the same table: 24.7 ms, untuned (tools/microbench/march_dev.hip).  At Nw = 5 the
+// two are level (1.37 against 1.28 ms on C2) and corr_volume stays.
+struct MarchPlan {
+    bool ok;
+    int nuy, npass, nstrips, wo, tw, nxb, nt;
+    int npa, npb, da, db;
+    unsigned a_slot, b_slot;
+    size_t lds;
+};
+#define UMPA_MARCH_NT 768
+#define UMPA_MARCH_NPT 4
+#define UMPA_MARCH_LA 2
+
+inline bool march_wanted(int Nw)
+{
+    const char* e = getenv("UMPA_HIP_MARCH");                         // 0: never, 1: wherever it is instantiated (Nw 6, 7)
+    if (e) return atoi(e) != 0 && (Nw == 6 || Nw == 7);
+    return Nw == 6 || Nw == 7;
+}
+
+inline MarchPlan march_plan(int Nw, int UJ, int K, int N1d)
+{
+    MarchPlan P;
+    memset(&P, 0, sizeof(P));
+    if (!(Nw == 6 || Nw == 7) || UJ > 33 || UJ < 3) return P;
+    P.nxb = UJ <= 17 ? 4 : 8;
+    const int nbe = 16 + P.nxb;
+    P.wo = (63 - 2 * Nw) / 4 * 4;
+    P.tw = (P.wo % 16 == 0) ? P.wo : 64;
+    P.nstrips = (N1d + P.wo - 1) / P.wo;
+    P.nt = UMPA_MARCH_NT;
+    P.npa = (K + 1) / 2;
+    P.npb = (K * 2 * nbe + 63) / 64;
+    if (P.npa + P.npb > UMPA_MARCH_NPT * (P.nt / 64)) return P;       // more staging instructions per step than the waves hold offsets for
+    P.a_slot = (unsigned)P.npa * 1024u;
+    P.b_slot = (unsigned)P.npb * 1024u;
+    for (int nuy = std::min(UJ, (P.nt / 16) / UJ); nuy >= 1; nuy--) {  // as many row offsets per pass as the waves and the LDS hold
+        const size_t lds = (size_t)(UMPA_MARCH_LA + 1) * P.a_slot + (size_t)(nuy + UMPA_MARCH_LA) * P.b_slot;
+        if (lds <= UMPA_LDS_BUDGET) { P.nuy = nuy; P.lds = lds; break; }
+    }
+    if (P.nuy < 1) return P;
+    P.npass = (UJ + P.nuy - 1) / P.nuy;
+    P.da = UMPA_MARCH_LA + 1; P.db = P.nuy + UMPA_MARCH_LA;
+    P.ok = true;
+    return P;
+}
+
+// the frames' byte offsets from the lowest frame address of each stack (positions folded in): false if a stack does not fit
+// 32-bit offsets up to the last image row the kernel may address
+inline bool march_offsets(const FrameDesc* hf, int K, int sigma, const FrameBox& box, std::vector<unsigned>& off,
+                          const char*& baseA, const char*& baseB)
+{
+    off.assign(2 * (size_t)K, 0u);
+    for (int st = 0; st < 2; st++) {
+        const bool sam = (st == 0) == (sigma > 0);                    // A = the stack whose window does not move (umpa_corr.h)
+        intptr_t lo = INTPTR_MAX, hi = INTPTR_MIN;
+        for (int k = 0; k < K; k++) {
+            const intptr_t p = (intptr_t)(sam ? hf[k].sam : hf[k].ref) - ((intptr_t)hf[k].pi * box.Wf + hf[k].pj) * 8;
+            lo = std::min(lo, p); hi = std::max(hi, p);
+        }
+        const uint64_t span = (uint64_t)(hi - lo) + ((uint64_t)box.r1 + 2) * (uint64_t)box.Wf * 8u;
+        if (span >= ((uint64_t)1 << 32) - 4096) return false;
+        for (int k = 0; k < K; k++)
+            off[(size_t)st * K + k] = (unsigned)((intptr_t)(sam ? hf[k].sam : hf[k].ref) - ((intptr_t)hf[k].pi * box.Wf + hf[k].pj) * 8 - lo);
+        (st == 0 ? baseA : baseB) = (const char*)lo;
+    }
+    return true;
+}
+
+template <int NW, int NXB>
+inline hipError_t launch_march_inst(const ModelDev& dev, const MarchArgs& A, const Sep1D& sep, const MarchPlan& P, hipStream_t s)
+{
+    auto kern = corr_march_kernel<NW, NXB, UMPA_MARCH_NPT, UMPA_MARCH_LA, UMPA_MARCH_NT, 3>;
+    static bool attr_set[64] = {};
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    {
+        std::lock_guard<std::mutex> lock(tiled_attr_mutex());
+        if (!attr_set[devid & 63]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, UMPA_LDS_BUDGET);
+            if (e != hipSuccess) return e;
+            attr_set[devid & 63] = true;
+        }
+    }
+    const int nitems = A.nstrips * A.nbands, grid = 8 * ((nitems + 7) / 8) * A.npass;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(UMPA_MARCH_NT), P.lds, s, dev, A, sep);
+    return hipGetLastError();
+}
+
+// one row chunk of the table; `fma`: the fp64 FMAs the launch executes (roofline accounting)
+inline hipError_t launch_march(const ModelDev& dev, MarchArgs A, const Sep1D& sep, const MarchPlan& P, hipStream_t s, double* fma)
+{
+    const int Nw = dev.Nw, UJ = 2 * dev.ms - 1, S = 2 * Nw + 1;
+    // bands: one workgroup per CU; as many bands as fill whole rounds of the chip, each paying 2 Nw rows of lead-in
+    const int ncu = device_cu_count();
+    int best_nb = 1; double best_cost = 1e300;
+    for (int nb = 1; nb <= 64 && nb <= A.rows; nb++) {
+        const double rounds = std::ceil((double)A.nstrips * A.npass * nb / ncu);
+        const double cost = rounds * (std::ceil((double)A.rows / nb) + 2 * Nw + 8);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_nb = nb; }
+    }
+    { const char* e = getenv("UMPA_HIP_MARCH_BANDS"); if (e && atoi(e) > 0) best_nb = atoi(e); }
+    A.nbands = best_nb; A.band_rows = (A.rows + best_nb - 1) / best_nb;
+    if (fma) {
+        double f = 0.0;
+        for (int b = 0; b < A.nbands; b++) {
+            const int rows = std::min(A.rows, (b + 1) * A.band_rows) - b * A.band_rows;
+            if (rows <= 0) continue;
+            const double steps = rows + 2 * Nw;
+            f += (double)A.nstrips * UJ * UJ * 64.0 * (steps * (dev.Na + S) + (double)rows * S);
+        }
+        *fma = f;
+    }
+    if (Nw == 6) return P.nxb == 4 ? launch_march_inst<6, 4>(dev, A, sep, P, s) : launch_march_inst<6, 8>(dev, A, sep, P, s);
+    return P.nxb == 4 ? launch_march_inst<7, 4>(dev, A, sep, P, s) : launch_march_inst<7, 8>(dev, A, sep, P, s);
+}
+
 // The tiles of the maps a region needs: its pixels, seen from the image, and max_shift around them (a map is read at the
 // pixel and at the pixel + shift).  Matches of a part of the image -- a ROI, one rectangle of a sample-stepping stack -- then
 // pay for their part of the maps only.
@@ -894,11 +1031,11 @@ inline size_t tiled_table_budget()
 // `piece_rows` > 0: row chunks of at most that many dense rows (a multiple of 32) even where the table budget would
 // allow more (the host-array entry point downloads the rows of chunk c while chunk c+1 is being matched, the multi-GPU
 // leg sends them to rank 0); `on_rows(xi_lo, xi_hi)` is called after the kernels of a chunk have been enqueued.
-struct FrameBox { int r0, r1, c0, c1, Wf; int slack; };   // slack: 1 if 8 readable bytes follow every frame row's last column
 
 inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int W, const FrameBox& box, const RegionArgs& A,
                        hipStream_t s, TiledTimers* tt, bool reuse_ref_maps,
-                       int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr)
+                       int piece_rows = 0, const std::function<void(int, int)>& on_rows = nullptr,
+                       const FrameDesc* host_frames = nullptr)      // a host copy of dev.frames (corr_march's staging offsets)
 {
     const int K = dev.Na, Nw = dev.Nw, ms = dev.ms, UJ = 2 * ms - 1;
     const size_t plane = (size_t)H * W;
@@ -926,7 +1063,20 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     // table rows are padded to whole 256-byte tile rows: every (tile, row) of a plane is then a run of whole, aligned
     // 128-byte lines (C2: 2028 -> 2048 doubles; UMPA_HIP_TABLE_ALIGN=1 packs the rows as round 3 did)
     static const int table_align = getenv("UMPA_HIP_TABLE_ALIGN") ? std::max(1, atoi(getenv("UMPA_HIP_TABLE_ALIGN"))) : 32;
-    const int N1p = (N1d + table_align - 1) / table_align * table_align;
+    int N1p = (N1d + table_align - 1) / table_align * table_align;
+    // wide windows: the table comes from corr_march (strip-blocked: [strip][rows][shift][tw], one "row" = nstrips * UJ^2 * tw doubles)
+    MarchPlan MP;
+    memset(&MP, 0, sizeof(MP));
+    const char* march_baseA = nullptr; const char* march_baseB = nullptr;
+    {
+        const char* od_env = getenv("UMPA_HIP_ONDEMAND");
+        const bool od_forced = od_env && atoi(od_env) != 0;           // (the on-demand stages are corr_volume's)
+        if (host_frames && march_wanted(Nw) && !od_forced) {
+            MP = march_plan(Nw, UJ, K, N1d);
+            if (MP.ok && !march_offsets(host_frames, K, dev.ref_mode ? -1 : 1, box, st.march_off_host, march_baseA, march_baseB)) MP.ok = false;
+        }
+    }
+    if (MP.ok) N1p = MP.nstrips * MP.tw;                               // doubles per dense row and shift
     const size_t row_bytes = (size_t)UJ * UJ * N1p * sizeof(double);
     long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
     if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
@@ -994,6 +1144,15 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     int ub = pick_ub(UJ);
     { const char* e = getenv("UMPA_HIP_UB"); if (e) ub = atoi(e); }      // tuning override: 9, 8, 7 or 5
     st.stat_n = 0; st.stat_total_passes = 0.0;
+    if (MP.ok) {                                                       // the frames' staging offsets (stable storage: the state's own vector)
+        if (st.march_off_cap < 2 * K) {
+            if (st.march_off) (void)hipFree(st.march_off);
+            st.march_off = nullptr; st.march_off_cap = 0;
+            if (hipMalloc((void**)&st.march_off, 2 * (size_t)K * sizeof(unsigned)) != hipSuccess) return -3;
+            st.march_off_cap = 2 * K;
+        }
+        if ((e = hipMemcpyAsync(st.march_off, st.march_off_host.data(), 2 * (size_t)K * sizeof(unsigned), hipMemcpyHostToDevice, s)) != hipSuccess) return (int)e;
+    }
     for (int drow0 = 0; drow0 < N0d; drow0 += (int)rows_chunk) {
         const int drows = (int)((N0d - drow0 < rows_chunk) ? N0d - drow0 : rows_chunk);
         CorrArgs CA;
@@ -1008,6 +1167,8 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         const int xi_hi = std::min(A.N0, (drow0 + drows - 1) / A.step0 + 1);
         ReplayArgs R;
         R.table = st.table; R.slot_stride = CA.slot_stride; R.drow0 = drow0; R.N1d = N1p;
+        R.strip_w = 0; R.tw = 0; R.drows = drows;
+        if (MP.ok) { R.strip_w = MP.wo; R.tw = MP.tw; R.slot_stride = (size_t)MP.tw; }
         R.row0 = xi_lo; R.rows = std::max(0, xi_hi - xi_lo);
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
         // frame count as a template constant where the map planes are 32-bit addressable (eval_lookup)
@@ -1026,6 +1187,23 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         auto corr = [&](const OdArgs& od) {
             CL.od = od;
             hipError_t ce = hipErrorInvalidValue;
+            if (MP.ok) {                                              // corr_march (od.mode is 0 here: the on-demand stages are corr_volume's)
+                MarchArgs MA;
+                memset(&MA, 0, sizeof(MA));
+                MA.table = st.table; MA.tw = MP.tw;
+                MA.org0 = A.org0; MA.org1 = A.org1; MA.row0 = drow0; MA.rows = drows; MA.N1 = N1d;
+                MA.sigma = CA.sigma;
+                MA.br0 = box.r0; MA.br1 = box.r1; MA.bc0 = box.c0; MA.bc1 = box.c1 + box.slack; MA.Wf = box.Wf;
+                MA.nstrips = MP.nstrips; MA.npass = MP.npass; MA.nuy = MP.nuy;
+                MA.npa = MP.npa; MA.npb = MP.npb; MA.a_slot = MP.a_slot; MA.b_slot = MP.b_slot; MA.da = MP.da; MA.db = MP.db;
+                MA.baseA = march_baseA; MA.baseB = march_baseB; MA.frame_off = st.march_off;
+                { const char* ab = getenv("UMPA_HIP_ABLATE_MARCH"); MA.ablate = ab ? atoi(ab) : 0; }
+                double fma = 0.0;
+                tic(9);
+                ce = launch_march(dev, MA, st.sep, MP, s, &fma);
+                toc(fma);
+                return ce;
+            }
             tic(3);
             UMPA_NW_SWITCH(Nw, (ce = launch_corr_nw<NWC>(ub, dev, CA, st.sep, s, CL)))
             toc(od.mode ? 0.0 : CL.fma_per_pass * ntiles * CL.npass);
@@ -1062,7 +1240,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         od.tc = CL.tc; od.ub = CL.ub; od.nbatch = CL.nbatch; od.npass = CL.npass; od.ntx = CL.ntx; od.nty = CL.nty;
         od.ub_inv = (65536 + CL.ub - 1) / CL.ub; od.nrow_inv = (65536 + CL.nrow - 1) / CL.nrow;
         OdBuffers OB;
-        if (od_enabled(ntiles, CL.npass, false) && !CA.ablate) {
+        if (!MP.ok && od_enabled(ntiles, CL.npass, false) && !CA.ablate) {
             if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
             if ((e = od_run_chunk(od, OB, s, corr, replay)) != hipSuccess) return (int)e;
             // the counters of this chunk, for the FMA count of a timed match and for umpa_hip_last_stats
