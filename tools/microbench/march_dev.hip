@@ -26,7 +26,7 @@ static float run(const ModelDev& dev, const MarchArgs& A, const Sep1D& sep, size
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     float best = 1e9f, sum = 0;
-    for (int r = 0; r < reps; r++) {
+    for (int r = 0; r < (getenv("REPS") ? atoi(getenv("REPS")) : reps); r++) {
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, 0, dev, A, sep);
         CK(hipEventRecord(e1));

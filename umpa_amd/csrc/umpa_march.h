@@ -11,18 +11,28 @@
 //     Nothing of the two filters goes through LDS: no plane writes, no transposes, no flush, one barrier per step.
 //   * No vertical halo: a patch row is staged and multiplied once per pass, not once per 32-row tile; the horizontal halo is
 //     64 / WO, WO = 52 at Nw = 5.
-//   * Staging is the job of ONE wave of the workgroup (the last): LDS-DMA of the rows LA steps ahead, counted s_waitcnt
-//     vmcnt, then the step's barrier.  The compute waves never wait on vmcnt, so their table stores (which count in the
-//     same in-order counter) stay in flight as long as they like.
-//   * LDS images are laid out for the reads: 16 lanes of a plane read 256 contiguous bytes per instruction ([even pairs | odd
-//     pairs]).  A shift by an odd number of columns would be a misaligned 16-byte read of B: such a plane works one column
-//     to the left instead -- A comes from a second image of the A row shifted by one column, B is read at the even shift
-//     below, the finished row moves back by one lane-column on its way out (DPP).  The two DPP rows that share the lane groups
-//     of a ds_read_b128 are always the planes (2m, 2m+1) of one row offset (or the last column offset of two row offsets):
-//     they read the same B addresses on complementary lanes and A / A' at the same bank phase: no bank conflicts.
-//   * The table is blocked by strips, [strip][row][shift][TW columns], TW * 8 bytes a multiple of 128: every store
-//     instruction writes whole, aligned lines (tools/microbench/table_store_rate.hip: 5.3 TB/s; 54-column runs at the
-//     region's row pitch: 1.3-2.9 TB/s).  Columns WO .. TW-1 of a block are padding.
+//   * Staging (LDS-DMA, 1 KiB per wave-instruction) is spread over ALL waves: instruction n of a step belongs to wave n mod NWV,
+//     the rows LA steps ahead.  A wave's table stores count in the same in-order vmcnt as its staging: the counted wait at
+//     the head of a step knows how many of either were issued since (exact counts, not a drain).  (One dedicated staging
+//     wave was tried: an LDS-DMA instruction costs its wave about 140 cycles to issue, C3's 23 per step bound the kernel.)
+//   * LDS images are laid out for the reads: a row of A or B is [frame][even pairs | odd pairs] (16-byte column pairs), so
+//     that the 16 lanes of a plane read 256 contiguous bytes per instruction.  A plane at an ODD column shift works one
+//     column to the left (columns 4l-1 .. 4l+2): its B reads are then the 16-byte aligned ones of the even shift below,
+//     its A columns come as four ds_read_b64, and the finished row moves back by one lane-column on its way out (DPP).
+//     The two DPP rows that share the lane groups of an LDS instruction are always the planes (2m, 2m+1) of one row offset
+//     (or the last, even column offset of two row offsets): they read the same B addresses on complementary lanes and A
+//     columns on complementary halves of the 16-byte slots -- no bank conflicts (SQ_LDS_BANK_CONFLICT = 0).
+//   * The table is blocked by strips, [strip][row][shift][TW columns], TW * 8 bytes a multiple of 128 where the window
+//     allows: a plane's row is a run of whole, aligned lines (tools/microbench/table_store_rate.hip: 54-column runs at the
+//     region's row pitch 1.3-2.9 TB/s, aligned runs 5.3 TB/s; plain stores: the L2 puts the two halves of a 64-byte piece
+//     together, non-temporal ones send them out separately).  replay_walk addresses either layout (ReplayArgs::strip_w).
+//
+// Where it stands (tools/microbench/march_dev.hip, one MI355X): C3 (4096 x 4096, 20 frames, Nw = 7, max_shift = 8) 24.7-25.8 ms
+// for the whole table against corr_volume's 28.9: LDS 45 % busy, VALU about 59 %, waves waiting 47 % of their cycles -- one
+// workgroup of 12 waves per CU (168 VGPRs: the ring of a 15-wide window alone takes 112) leaves nothing to run beside a
+// barrier.  C2 (Nw = 5, two workgroups of 7 waves per CU): 1.29-1.46 ms against corr_volume's 1.28 -- level, so windows up
+// to 11 pixels stay on corr_volume.  What both kernels run into is the CU's vector-memory path: staged bytes plus stored
+// bytes leave at about 19 GB/s per CU (4.9 TB/s over the chip) whichever kernel issues them.
 //
 // Sums are formed in another order than corr_volume's (frames first, then rows, then columns); parity is on results.
 #pragma once
@@ -221,28 +231,39 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
             UMPA_LDS_AS const char* pa = lds + ldsA + (unsigned)ia * A.a_slot;
             UMPA_LDS_AS const char* pb = lds + ldsB + (unsigned)ibl * A.b_slot;
             unsigned q0 = (unsigned)(size_t)pa + a_o0, q1 = (unsigned)((int)(size_t)pa + a_o13), q2 = (unsigned)(size_t)pa + a_o2;   // LDS byte addresses
-            UMPA_LDS_AS const char* r1 = pb + b_off1; UMPA_LDS_AS const char* r2 = pb + b_off2;
-            // (the four A reads are written out: left to itself the compiler pairs them into ds_read2_b64 / ds_read2st64_b64,
-            //  which run at half the LDS rate -- C2: frame loop 0.7 -> 1.5 ms)
+            unsigned r1 = (unsigned)(size_t)pb + b_off1, r2 = (unsigned)(size_t)pb + b_off2;
+            // One frame: six LDS reads in the order they are used -- columns 0, 1 of A, their B pair, columns 2, 3, their B pair --
+            // and two counted waits, so that the first two FMAs run while the second half is still on its way.  (Everything is
+            // written out: left to itself the compiler pairs the A reads into ds_read2_b64 / ds_read2st64_b64, which run at half
+            // the LDS rate -- C2: frame loop 0.7 -> 1.5 ms.)
             auto frame = [&](auto FA, auto FB) {
                 constexpr int fa = decltype(FA)::value, fb = decltype(FB)::value;
                 double a0, a1, a2, a3;
-                asm volatile("ds_read_b64 %0, %4 offset:%7\n\tds_read_b64 %1, %5 offset:%8\n\tds_read_b64 %2, %6 offset:%7\n\tds_read_b64 %3, %5 offset:%9"
-                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
-                             : "v"(q0), "v"(q1), "v"(q2), "n"(fa), "n"(fa + 8), "n"(fa + 264) : "memory");
-                const pair_t b0 = *(UMPA_LDS_AS const pair_t*)(r1 + fb), b1 = *(UMPA_LDS_AS const pair_t*)(r2 + fb);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "memory");
+                pair_t b0, b1;
+                asm volatile("ds_read_b64 %0, %6 offset:%11\n\tds_read_b64 %1, %7 offset:%12\n\tds_read_b128 %4, %9 offset:%14\n\t"
+                             "ds_read_b64 %2, %8 offset:%11\n\tds_read_b64 %3, %7 offset:%13\n\tds_read_b128 %5, %10 offset:%14"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1)
+                             : "v"(q0), "v"(q1), "v"(q2), "v"(r1), "v"(r2), "n"(fa), "n"(fa + 8), "n"(fa + 264), "n"(fb) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a0), "+v"(a1), "+v"(b0) :: "memory");
                 p[0] = fma(a0, b0[0], p[0]); p[1] = fma(a1, b0[1], p[1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a2), "+v"(a3), "+v"(b1) :: "memory");
                 p[2] = fma(a2, b1[0], p[2]); p[3] = fma(a3, b1[1], p[3]);
             };
+            using I0 = std::integral_constant<int, 0>;
             int k = 0;
-            for (; k + 2 <= K; k += 2) {
-                frame(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            for (; k + 4 <= K; k += 4) {                              // (frame offsets as immediates: one address update per four frames)
+                frame(I0{}, I0{});
                 frame(std::integral_constant<int, C::APF * 16>{}, std::integral_constant<int, C::BPF * 16>{});
-                q0 += 2 * C::APF * 16; q1 += 2 * C::APF * 16; q2 += 2 * C::APF * 16;
-                r1 += 2 * C::BPF * 16; r2 += 2 * C::BPF * 16;
+                frame(std::integral_constant<int, 2 * C::APF * 16>{}, std::integral_constant<int, 2 * C::BPF * 16>{});
+                frame(std::integral_constant<int, 3 * C::APF * 16>{}, std::integral_constant<int, 3 * C::BPF * 16>{});
+                q0 += 4 * C::APF * 16; q1 += 4 * C::APF * 16; q2 += 4 * C::APF * 16;
+                r1 += 4 * C::BPF * 16; r2 += 4 * C::BPF * 16;
             }
-            if (k < K) frame(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            for (; k < K; k++) {
+                frame(I0{}, I0{});
+                q0 += C::APF * 16; q1 += C::APF * 16; q2 += C::APF * 16;
+                r1 += C::BPF * 16; r2 += C::BPF * 16;
+            }
         }
         ia = ia + 1 == A.da ? 0 : ia + 1;
         ib = ib + 1 == A.db ? 0 : ib + 1;
