@@ -6,7 +6,7 @@ from collections import defaultdict
 def short(name):
     n = name.split("(")[0]
     for key in ("prep_maps", "corr_volume_queue", "corr_volume", "replay_walk", "corr_masked_queue", "corr_masked", "replay_cost",
-                "blur_tiles", "od_list", "match_direct", "match_staged", "coverage", "cost_one", "spfit"):
+                "blur_tiles", "od_list", "corr_march", "match_direct", "match_staged", "coverage", "cost_one", "spfit"):
         if key in n:
             return key
     return n[:60]
