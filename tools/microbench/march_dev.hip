@@ -15,10 +15,10 @@ using namespace umpa;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-template <int NW, int NXB, int NPD, int LA, int NT, int WPS>
+template <int NW, int NXB, int NPD, int LA, int NT, int WPS, int SPB = 1>
 static float run(const ModelDev& dev, const MarchArgs& A, const Sep1D& sep, size_t lds, int grid, int reps)
 {
-    auto kern = corr_march_kernel<NW, NXB, NPD, LA, NT, WPS>;
+    auto kern = corr_march_kernel<NW, NXB, NPD, LA, NT, WPS, SPB>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -106,7 +106,8 @@ int main(int argc, char** argv)
     A.a_slot = A.npa * 1024;
     A.b_slot = A.npb * 1024;
     const int LA = getenv("LA") ? atoi(getenv("LA")) : 2;
-    A.da = LA + 1; A.db = nuy + LA;
+    const int SPB = getenv("SPB") ? atoi(getenv("SPB")) : 1;
+    A.da = SPB > 1 ? 2 * SPB : LA + 1; A.db = SPB > 1 ? nuy - 1 + 2 * SPB : nuy + LA;
     const bool sam_is_A = sigma > 0;
     A.baseA = (const char*)(sam_is_A ? dsam : dref); A.baseB = (const char*)(sam_is_A ? dref : dsam);
     std::vector<unsigned> foff(2 * K);
@@ -123,11 +124,14 @@ int main(int argc, char** argv)
 
     float best = 0;
     const int reps = 20;
-    if (Nw == 5 && NT == 448 && npt <= 2 && LA == 2) best = run<5, 2, 2, 2, 448, 4>(dev, A, sep, lds, grid, reps);
+    if (Nw == 5 && NT == 448 && npt <= 2 && LA == 2 && SPB == 1) best = run<5, 2, 2, 2, 448, 4>(dev, A, sep, lds, grid, reps);
     else if (Nw == 5 && NT == 448 && npt <= 2 && LA == 3) best = run<5, 2, 2, 3, 448, 4>(dev, A, sep, lds, grid, reps);
     else if (Nw == 5 && NT == 768 && npt <= 1 && LA == 2) best = run<5, 2, 1, 2, 768, 3>(dev, A, sep, lds, grid, reps);
     else if (Nw == 5 && NT == 576 && npt <= 2 && LA == 2) best = run<5, 2, 2, 2, 576, 3>(dev, A, sep, lds, grid, reps);
     else if (Nw == 7 && NT == 512 && npt <= 3 && LA == 2) best = run<7, 4, 3, 2, 512, 2>(dev, A, sep, lds, grid, reps);
+    else if (Nw == 7 && NT == 768 && npt <= 2 && LA == 2 && SPB == 2) best = run<7, 4, 2, 2, 768, 3, 2>(dev, A, sep, lds, grid, reps);
+    else if (Nw == 7 && NT == 768 && npt <= 2 && LA == 2 && SPB == 3) best = run<7, 4, 2, 2, 768, 3, 3>(dev, A, sep, lds, grid, reps);
+    else if (Nw == 5 && NT == 448 && npt <= 2 && LA == 2 && SPB == 2) best = run<5, 2, 2, 2, 448, 4, 2>(dev, A, sep, lds, grid, reps);
     else if (Nw == 7 && NT == 768 && npt <= 2 && LA == 2) best = run<7, 4, 2, 2, 768, 3>(dev, A, sep, lds, grid, reps);
     else if (Nw == 7 && NT == 768 && npt <= 2 && LA == 3) best = run<7, 4, 2, 3, 768, 3>(dev, A, sep, lds, grid, reps);
     else { printf("no instantiation for Nw=%d NT=%d npt=%d\n", Nw, NT, npt); return 1; }

@@ -129,7 +129,14 @@ struct CorrCfg {
             if ((QR * p) % 16 == (QB / 2) % 16) return p;
         return least | 1;                                 // (even half-window: no such pitch)
     }
-    static constexpr int PA = pitch_for(QC / 2), PB = pitch_for(BW / 2);
+#ifndef UMPA_CORR_PB_MIN
+#define UMPA_CORR_PB_MIN 1
+#endif
+    // Round 4: the three-row-offset shapes stage the B image at its LEAST odd pitch (25 pieces instead of pitch_for's 29 on C2):
+    // 8 % fewer staged bytes and four LDS-DMA instructions per thread and frame instead of five.  The kernel is bound by the
+    // bytes through the CU's vector-memory path (DESIGN.md 4.3 "round 4"), not by the LDS bank conflicts the wider pitch avoids:
+    // corr_volume 1.277 / 1.282 -> 1.254 / 1.264 ms on one box, back to back (tools/ab_libs.sh; -DUMPA_CORR_PB_MIN=0 restores 29).
+    static constexpr int PA = pitch_for(QC / 2), PB = (UMPA_CORR_PB_MIN && RO == 3) ? ((BW / 2) | 1) : pitch_for(BW / 2);
     // pieces of one staged frame: A image, then B image from a multiple of 64 pieces on -- a wave-instruction (64 pieces)
     // then reads one stack only, and its base address is a scalar (SGPR base + 32-bit lane offset)
     static constexpr int APIECES = (QR * PA + 63) & ~63;

@@ -4,13 +4,13 @@
 // patch rows of the band one row per step; a pass is NUY consecutive row offsets x every column offset of the search range.
 //
 //   * 16 lanes (one DPP row) x 4 columns = the 64 patch columns of ONE plane (shift); the compute waves of a workgroup hold
-//     NUY * (2 ms - 1) planes.  Per step a thread forms its 4 products summed over the frames (operands by ds_read_b128 out of
-//     a ring of staged rows), feeds them into the window's ROW filter kept as a ring of 2 Nw + 1 running sums in registers
+//     NUY * (2 ms - 1) planes.  Per step a thread forms its 4 products summed over the frames (operands out of rings of staged
+//     rows: A by four ds_read_b64, B by two ds_read_b128 per frame), feeds them into the window's ROW filter kept as a ring of 2 Nw + 1 running sums in registers
 //     (out[r] += hr[t] * P[r + t]: the sum an output row is waiting for grows by one tap per step), and runs the row that
 //     completes through the COLUMN filter with its neighbours' values fetched by DPP row shifts (lane l + n of the same 16).
 //     Nothing of the two filters goes through LDS: no plane writes, no transposes, no flush, one barrier per step.
 //   * No vertical halo: a patch row is staged and multiplied once per pass, not once per 32-row tile; the horizontal halo is
-//     64 / WO, WO = 52 at Nw = 5.
+//     64 / WO, WO = 48 at Nw = 6 and 7.
 //   * Staging (LDS-DMA, 1 KiB per wave-instruction) is spread over ALL waves: instruction n of a step belongs to wave n mod NWV,
 //     the rows LA steps ahead.  A wave's table stores count in the same in-order vmcnt as its staging: the counted wait at
 //     the head of a step knows how many of either were issued since (exact counts, not a drain).  (One dedicated staging
@@ -92,7 +92,11 @@ __device__ __forceinline__ void wait_vmcnt_rt(int n)     // (wave-uniform n)
 }
 
 // NT threads, every wave computes and stages.  NPT: upper bound of the LDS-DMA instructions of one wave per step.
-template <int NW, int NXB, int NPT, int LA, int NT, int WPS>
+// SPB: steps per workgroup barrier.  1: a barrier per step, rows LA steps ahead (ring depths da = LA + 1, db = nuy + LA).
+// 2 and more: the steps come in intervals of SPB; at the head of an interval the rows of the whole interval have landed (they
+// were issued at the head of the one before), one barrier, the rows of the next interval are issued; inside an interval the
+// waves run free, up to SPB steps apart (da = 2 SPB, db = nuy - 1 + 2 SPB).
+template <int NW, int NXB, int NPT, int LA, int NT, int WPS, int SPB = 1>
 __global__ void __launch_bounds__(NT, WPS)
 corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
 {
@@ -168,7 +172,7 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
     // (ring depths da = LA + 1, db = nuy + LA: the rows staged at step y go into the slots step y - 1 has just given up)
     for (int i = 0; i + 1 < A.nuy; i++) issue_rows(0, i, 0, i, false);
 #pragma unroll
-    for (int s = 0; s < LA; s++) issue_rows(s, s + A.nuy - 1, s, s + A.nuy - 1, true);
+    for (int s = 0; s < (SPB > 1 ? SPB : LA); s++) issue_rows(s, s + A.nuy - 1, s, s + A.nuy - 1, true);
 
     // ---- DPP row r -> plane: the first nuy * (UJ - 1) rows are (row offset, column offsets 0 .. UJ-2), pairs (2m, 2m+1) on rows
     // (2i, 2i+1); then the last column offset (even) of every row offset.  Rows past the pass idle.
@@ -211,20 +215,87 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
     // the table stores of this wave per step that completes a row: they count in vmcnt like the LDS-DMA
     const int st_w = __builtin_amdgcn_ballot_w64(st_ok) != 0 ? 2 : 0;
 
+    // (Tried with SPB = 2 and not kept: the upper half of the waves one phase behind the lower half -- filters and stores of step
+    //  y - 1 before the products of step y -- so that one wave's LDS-bound frame loop would meet another's VALU-bound filters:
+    //  C3 23.7 -> 25.1 ms, C2 1.43 -> 1.54.  SPB = 2 itself: C3 24.1 -> 23.7 ms for 24 KB more LDS; the library runs SPB = 1.)
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
+    // the row filter takes the products of step ys; the row that completes goes through the column filter and out
+    auto filter_and_store = [&](int ys) {
+            if (A.ablate & 4) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) ring[0][c] += p[c];
+                return;
+            }
+            // ---- row filter: out[r] = sum_t hr[t] P[r + t].  The row that started 2 Nw steps ago completes; every other sum moves
+            // one place up the ring as it takes its next tap (v_fma with the destination beside the addend: no copies)
+            double v[4 + 4 * C::NNB];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                v[c] = fma(sep.hr[S - 1], p[c], ring[S - 2][c]);
+#pragma unroll
+                for (int t = S - 2; t >= 1; t--) ring[t][c] = fma(sep.hr[t], p[c], ring[t - 1][c]);
+                ring[0][c] = sep.hr[0] * p[c];
+            }
+            if (ys < 2 * NW) return;                                      // (wave-uniform) nothing completes yet
+            // ---- column filter of the completed row: the 2 Nw values to the right come from lanes l+1 .. l+NNB
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                v[4 + c] = dpp_row_shl<1>(v[c]);
+                if (C::NNB >= 2 && 8 + c < 4 + 2 * NW) v[8 + c] = dpp_row_shl<2>(v[c]);
+                if (C::NNB >= 3 && 12 + c < 4 + 2 * NW) v[12 + c] = dpp_row_shl<3>(v[c]);
+                if (C::NNB >= 4 && 16 + c < 4 + 2 * NW) v[16 + c] = dpp_row_shl<4>(v[c]);
+            }
+            double o[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double acc = sep.hc[0] * v[c];
+#pragma unroll
+                for (int t = 1; t < S; t++) acc = fma(sep.hc[t], v[c + t], acc);
+                o[c] = acc;
+            }
+            // a plane at an odd shift holds columns 4l-1 .. 4l+2: its column 4l+3 is the next lane's first value
+            {
+                const double nx = dpp_row_shl<1>(o[0]);
+                const double o0 = odd ? o[1] : o[0], o1 = odd ? o[2] : o[1], o2 = odd ? o[3] : o[2], o3 = odd ? nx : o[3];
+                o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+            }
+            // ---- table row r_lo + y - 2 Nw
+            // (plain stores: each instruction writes half of every 64 bytes, the L2 puts the lines together; non-temporal stores of
+            //  this shape go out as partial lines -- tools/microbench/table_store_rate.hip: 2.5 against 4.2-6.8 TB/s)
+            if (st_ok) {
+                UMPA_GLOBAL char* dst = tbase + (size_t)(ys - 2 * NW) * row_pitch;     // (wave-uniform)
+                pair_t v0, v1;
+                v0[0] = o[0]; v0[1] = o[1]; v1[0] = o[2]; v1[1] = o[3];
+                *reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst + lane_off) = v0;
+                *reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst + lane_off + 16) = v1;
+            }
+    };
     for (int y = 0; y < nsteps; y++) {
         // the rows of step y were issued LA steps ago; since then this wave has issued the rows of LA - 1 further steps (none
         // for steps past the end) and the table stores of those of the steps y - LA .. y - 1 that completed a row
-        {
+        if constexpr (SPB == 1) {
             const int later = min(LA - 1, max(0, nsteps - 1 - y));
             wait_vmcnt_rt(later * cnt_w + st_w * max(0, min(LA, y - 2 * NW)));
-        }
-        lds_barrier();                                                // everyone's pieces of step y are in; step y - 1 has been read
-        {
+            lds_barrier();                                            // everyone's pieces of step y are in; step y - 1 has been read
             const int ja = ia == 0 ? A.da - 1 : ia - 1, jb = ib == 0 ? A.db - 1 : ib - 1;
             if (y + LA < nsteps) issue_rows(y + LA, y + LA + A.nuy - 1, ja, jb, true);
+        } else if (y % SPB == 0) {
+            // head of an interval: its rows were issued at the head of the one before; since then this wave has only issued the
+            // table stores of that interval's steps that completed a row
+            wait_vmcnt_rt(st_w * max(0, min(SPB, y - 2 * NW)));
+            lds_barrier();                                            // the interval's rows are in; the previous interval has been read
+#pragma unroll
+            for (int q = 0; q < SPB; q++) {
+                const int yn = y + SPB + q;
+                if (yn < nsteps) {
+                    int ja = ia + SPB + q; ja -= ja >= A.da ? A.da : 0;
+                    int jb = ib + SPB + q + A.nuy - 1; jb -= jb >= A.db ? A.db : 0; jb -= jb >= A.db ? A.db : 0;
+                    issue_rows(yn, yn + A.nuy - 1, ja, jb, true);
+                }
+            }
         }
         // ---- products of patch row y, summed over the frames
-        double p[4] = {0.0, 0.0, 0.0, 0.0};
+        p[0] = p[1] = p[2] = p[3] = 0.0;
         if (!(A.ablate & 2)) {
             int ibl = ib + uyl;
             if (ibl >= A.db) ibl -= A.db;
@@ -267,54 +338,7 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
         }
         ia = ia + 1 == A.da ? 0 : ia + 1;
         ib = ib + 1 == A.db ? 0 : ib + 1;
-        if (A.ablate & 4) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) ring[0][c] += p[c];
-            continue;
-        }
-        // ---- row filter: out[r] = sum_t hr[t] P[r + t].  The row that started 2 Nw steps ago completes; every other sum moves
-        // one place up the ring as it takes its next tap (v_fma with the destination beside the addend: no copies)
-        double v[4 + 4 * C::NNB];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            v[c] = fma(sep.hr[S - 1], p[c], ring[S - 2][c]);
-#pragma unroll
-            for (int t = S - 2; t >= 1; t--) ring[t][c] = fma(sep.hr[t], p[c], ring[t - 1][c]);
-            ring[0][c] = sep.hr[0] * p[c];
-        }
-        if (y < 2 * NW) continue;                                      // (wave-uniform) nothing completes yet
-        // ---- column filter of the completed row: the 2 Nw values to the right come from lanes l+1 .. l+NNB
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            v[4 + c] = dpp_row_shl<1>(v[c]);
-            if (C::NNB >= 2 && 8 + c < 4 + 2 * NW) v[8 + c] = dpp_row_shl<2>(v[c]);
-            if (C::NNB >= 3 && 12 + c < 4 + 2 * NW) v[12 + c] = dpp_row_shl<3>(v[c]);
-            if (C::NNB >= 4 && 16 + c < 4 + 2 * NW) v[16 + c] = dpp_row_shl<4>(v[c]);
-        }
-        double o[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            double acc = sep.hc[0] * v[c];
-#pragma unroll
-            for (int t = 1; t < S; t++) acc = fma(sep.hc[t], v[c + t], acc);
-            o[c] = acc;
-        }
-        // a plane at an odd shift holds columns 4l-1 .. 4l+2: its column 4l+3 is the next lane's first value
-        {
-            const double nx = dpp_row_shl<1>(o[0]);
-            const double o0 = odd ? o[1] : o[0], o1 = odd ? o[2] : o[1], o2 = odd ? o[3] : o[2], o3 = odd ? nx : o[3];
-            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
-        }
-        // ---- table row r_lo + y - 2 Nw
-        // (plain stores: each instruction writes half of every 64 bytes, the L2 puts the lines together; non-temporal stores of
-        //  this shape go out as partial lines -- tools/microbench/table_store_rate.hip: 2.5 against 4.2-6.8 TB/s)
-        if (st_ok) {
-            UMPA_GLOBAL char* dst = tbase + (size_t)(y - 2 * NW) * row_pitch;     // (wave-uniform)
-            pair_t v0, v1;
-            v0[0] = o[0]; v0[1] = o[1]; v1[0] = o[2]; v1[1] = o[3];
-            *reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst + lane_off) = v0;
-            *reinterpret_cast<UMPA_GLOBAL table_pair_t*>(dst + lane_off + 16) = v1;
-        }
+        filter_and_store(y);
     }
     wait_vmcnt<0>();
     if (A.ablate & 4) {
