@@ -531,6 +531,11 @@ def test_masked_models_against_the_oracle(hip_ns, port_ns, cfg):
     dict(H=300, W=700, K=5, Nw=5, ms=5, df=True, amp=3.5, assign="sam", mask=False, mk=dict()),
     dict(H=330, W=400, K=4, Nw=4, ms=5, df=True, amp=3.5, assign="sam", mask=True, mk=dict()),
     dict(H=330, W=400, K=4, Nw=4, ms=5, df=False, amp=3.5, assign="ref", mask=True, mk=dict(step=2)),
+    # windows of 13 / 15 pixels: corr_march's units are (strip, band, pass); the prediction is a lattice of sample pixels
+    # (od_run_chunk_march); bands of 64 rows so that these small images have several
+    dict(H=420, W=520, K=4, Nw=7, ms=8, df=True, amp=6.0, assign="sam", mask=False, mk=dict(), march_rows=64),
+    dict(H=380, W=300, K=3, Nw=6, ms=6, df=False, amp=4.5, assign="ref", mask=False, mk=dict(step=2, dxdy=(1, -1)), march_rows=64),
+    dict(H=300, W=410, K=5, Nw=7, ms=10, df=True, amp=7.5, assign="ref", mask=False, mk=dict(), march_rows=96),
 ])
 def test_on_demand_table_passes_change_nothing(hip_ns, monkeypatch, cfg):
     """umpa_ondemand.h: only the (tile, pass) units of the shift table that walks read are computed -- seed tiles predict,
@@ -545,6 +550,8 @@ def test_on_demand_table_passes_change_nothing(hip_ns, monkeypatch, cfg):
         mask = (np.random.default_rng(2).random(sam.shape) < 0.93).astype(np.float64)
     cls = hip_ns.UMPAModelDF if cfg["df"] else hip_ns.UMPAModelNoDF
     out, stats = {}, {}
+    if "march_rows" in cfg:
+        monkeypatch.setenv("UMPA_HIP_MARCH_OD_ROWS", str(cfg["march_rows"]))
     for od in ("0", "1"):
         monkeypatch.setenv("UMPA_HIP_ONDEMAND", od)
         m = cls(sam, ref, mask_list=mask, window_size=cfg["Nw"], max_shift=cfg["ms"])
@@ -557,7 +564,12 @@ def test_on_demand_table_passes_change_nothing(hip_ns, monkeypatch, cfg):
     for k in out["0"]:
         assert np.array_equal(out["0"][k], out["1"][k], equal_nan=True), k
     assert stats["0"][0] == stats["0"][1] and stats["0"][2] == 0          # exhaustive: every unit, nothing parked
-    assert stats["1"][1] == stats["0"][1] and stats["1"][0] < stats["1"][1], stats   # (harsh fields on small images: few passes go unread)
+    if "march_rows" in cfg:
+        # (strip, band, pass) units: a pass is two or three row offsets deep and every walk's 4 x 4 gather reaches two rows past its
+        # minimum, so on images this small every unit may be needed; what is pinned is the bookkeeping and the repair rounds
+        assert 0 < stats["1"][0] <= stats["1"][1], stats
+    else:
+        assert stats["1"][1] == stats["0"][1] and stats["1"][0] < stats["1"][1], stats   # (harsh fields on small images: few passes go unread)
     assert stats["1"][2] > 0, stats                                       # some walks were parked and run again
 
 

@@ -1392,7 +1392,7 @@ int umpa_hip_last_stats(umpa_hip_model* m, double* out4)
     for (int q = 0; q < st.stat_n; q++) {
         done += st.stat_slots[q][OD_C_DONE];
         missed += st.stat_slots[q][OD_C_TILES];                          // tiles whose prediction fell short (stage 0)
-        for (int r = 0; r < OD_ROUNDS; r++) parked += st.stat_slots[q][8 * r + OD_C_PX];   // walks started again, all rounds
+        for (int r = 0; r + 1 < OD_STAGES; r++) parked += st.stat_slots[q][8 * r + OD_C_PX];   // walks started again, all rounds
     }
     out4[0] = st.stat_n ? done : st.stat_total_passes;
     out4[1] = st.stat_total_passes;

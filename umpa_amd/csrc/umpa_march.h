@@ -56,6 +56,17 @@ struct MarchArgs {
     const char* baseB;
     const unsigned* frame_off;   // [2][Na]: byte offset of frame k's image origin (position folded in) from baseA / baseB
     int ablate;               // diagnostics: 1 no DMA, 2 no frame loop, 4 no filters, 8 no stores
+    // which (strip, band, pass) units the launch computes (on-demand passes, umpa_ondemand.h: a unit = a "tile" lin = band *
+    // nstrips + strip and a pass):
+    //   items == nullptr: the static grid, every (strip, band) x the passes pass0 .. pass0 + npass_run - 1;
+    //   items != nullptr: the work list ((lin << 8) | pass), *nitems entries; the grid has a slot for every unit there could be
+    //   and the workgroups past the list's end leave at once.
+    // done / ndone (or null): the unit's bit is set in done[lin] and *ndone counted when its planes are written (read by later launches).
+    const int* items;
+    const int* nitems;
+    unsigned long long* done;
+    int* ndone;
+    int pass0, npass_run;
 };
 
 template <int NW, int NXB>
@@ -109,9 +120,19 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
     const int tid = threadIdx.x;
     const int ms = m.ms, UJ = 2 * ms - 1, K = m.Na;
     // ---- (strip, band, pass) of this workgroup: the passes of one (strip, band) on consecutive slots of one XCD
-    const int nitems = A.nstrips * A.nbands, per_xcd = (nitems + 7) >> 3;
-    const int seq = blockIdx.x >> 3, item = (blockIdx.x & 7) * per_xcd + seq / A.npass, pass = seq % A.npass;
-    if (seq / A.npass >= per_xcd || item >= nitems) return;
+    int item, pass;
+    if (A.items) {                                                    // the list cut into 8 contiguous ranges, one per XCD
+        const int n = __builtin_amdgcn_readfirstlane(gp(A.nitems)[0]), per_xcd = (n + 7) >> 3;
+        const int seq = blockIdx.x >> 3, idx = (blockIdx.x & 7) * per_xcd + seq;
+        if (seq >= per_xcd || idx >= n) return;
+        const int it = __builtin_amdgcn_readfirstlane(gp(A.items)[idx]);
+        item = it >> 8; pass = it & 255;
+    } else {
+        const int nitems = A.nstrips * A.nbands, per_xcd = (nitems + 7) >> 3;
+        const int seq = blockIdx.x >> 3;
+        item = (blockIdx.x & 7) * per_xcd + seq / A.npass_run; pass = A.pass0 + seq % A.npass_run;
+        if (seq / A.npass_run >= per_xcd || item >= nitems) return;
+    }
     const int strip = item % A.nstrips, band = item / A.nstrips;
     const int r_lo = band * A.band_rows, r_hi = min(A.rows, r_lo + A.band_rows);   // rows of this launch's chunk
     if (r_lo >= r_hi) return;
@@ -341,6 +362,10 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
         filter_and_store(y);
     }
     wait_vmcnt<0>();
+    if (A.done && tid == 0) {
+        atomicOr(A.done + item, 1ull << pass);
+        if (A.ndone) atomicAdd(A.ndone, 1);
+    }
     if (A.ablate & 4) {
         if (plane_ok && tid == 0) *(UMPA_GLOBAL double*)tbase = ring[0][0] + ring[0][1] + ring[0][2] + ring[0][3];
     }

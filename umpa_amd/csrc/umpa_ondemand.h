@@ -28,6 +28,8 @@ namespace umpa {
 
 #define OD_SP 4                       // seed-tile spacing
 #define OD_ROUNDS 3                   // repair rounds; the last one computes everything that is still missing
+#define OD_SAMPLE_ROUNDS 3            // corr_march's schedule (od_run_chunk_march): rounds of the sample lattice
+#define OD_STAGES 12                  // counter blocks of a chunk (>= OD_ROUNDS + 1 and >= OD_SAMPLE_ROUNDS + OD_ROUNDS + 3)
 // counters: int[8] per stage, stage 0 = steps 1-3, stage r = repair round r.
 #define OD_C_TILES  0                 // missed tiles listed by the replay of this stage
 #define OD_C_PX     1                 // pixels parked by the replay of this stage
@@ -48,6 +50,11 @@ struct OdArgs {
                                       // replay kernels: 0 no on-demand, 1 seed-tile pixels (compact grid; record visited), 2 the other pixels
                                       // (park on a miss), 3 persistent grid over px_in (park on a miss)
     int tc, ub, nbatch, npass, ntx, nty;   // pass / tile geometry of the table kernel
+    int tr;                           // rows of a tile: 32 (corr_volume, corr_masked) or corr_march's band height (a tile = strip x band)
+    int sub;                          // replay mode 2: > 1 = only the pixels of a lattice, every sub-th in both directions (corr_march's
+                                      // sample stage); 0, 1: every pixel
+    int pass0, npass_run;             // corr_march, mode 0: the static grid computes these passes only (npass_run = 0: all)
+    int alone;                        // 1: a parked pixel asks for the pass it missed alone, 0: and for its neighbours in the row-offset direction
     int r0, c0;                       // seed tiles: ty % OD_SP == r0 and tx % OD_SP == c0
     int ub_inv;                       // ceil(2^16 / ub): x / ub = (x * ub_inv) >> 16 for 0 <= x < 70
     int nrow_inv;                     // the same for the row offsets per pass
@@ -164,7 +171,7 @@ __device__ __forceinline__ bool od_begin(const OdArgs& od, int dense_row, int de
 {
     L.avail = ~0ull; L.vis = 0; L.lin = 0; L.miss = false; L.miss_pass = 0;
     if (od.mode == 0) return true;
-    const int ty = dense_row >> 5, tx = dense_col / od.tc;          // (once per pixel)
+    const int ty = od.tr == 32 ? dense_row >> 5 : dense_row / od.tr, tx = dense_col / od.tc;          // (once per pixel)
     L.lin = ty * od.ntx + tx;
     if (od.mode == 2 && od_is_seed(od, ty, tx)) return false;
     L.avail = gp(od.done)[L.lin];
@@ -204,8 +211,10 @@ __device__ __forceinline__ void od_park(const OdArgs& od, const OdLane& L, int p
 {
     gpw(od.px_out)[atomicAdd(od.cnt_out + OD_C_PX, 1)] = px;
     unsigned long long want = 1ull << L.miss_pass;
-    if (L.miss_pass >= od.nbatch) want |= 1ull << (L.miss_pass - od.nbatch);
-    if (L.miss_pass + od.nbatch < od.npass) want |= 1ull << (L.miss_pass + od.nbatch);
+    if (od.alone == 0) {                                             // (corr_march's passes are several row offsets deep already)
+        if (L.miss_pass >= od.nbatch) want |= 1ull << (L.miss_pass - od.nbatch);
+        if (L.miss_pass + od.nbatch < od.npass) want |= 1ull << (L.miss_pass + od.nbatch);
+    }
     atomicOr(od.visited + L.lin, want);
     if (atomicExch(od.tile_flag + L.lin, 1) == 0) gpw(od.tile_out)[atomicAdd(od.cnt_out + OD_C_TILES, 1)] = L.lin;
 }

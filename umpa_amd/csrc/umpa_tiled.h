@@ -414,7 +414,9 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
     } else {
         if (!first) break;
         xj = blockIdx.x * 64 + threadIdx.x;
-        xi = R.row0 + blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
+        xi = blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
+        if (OD && od.sub > 1) { xj = xj * od.sub + (od.sub >> 1); xi = xi * od.sub + (od.sub >> 1); }   // the sample lattice (a compact grid)
+        xi += R.row0;
         live = xi < R.row0 + R.rows && xj < A.N1;
     }
     const size_t px = (size_t)xi * A.pitch + xj;                     // in the output arrays
@@ -849,9 +851,25 @@ inline hipError_t launch_march_inst(const ModelDev& dev, const MarchArgs& A, con
             attr_set[devid & 63] = true;
         }
     }
-    const int nitems = A.nstrips * A.nbands, grid = 8 * ((nitems + 7) / 8) * A.npass;
+    const int nitems = A.nstrips * A.nbands;
+    // (work list: a slot for every unit there could be; the workgroups past the list's end leave at once)
+    const int grid = A.items ? 8 * ((nitems * A.npass + 7) / 8) : 8 * ((nitems + 7) / 8) * A.npass_run;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(UMPA_MARCH_NT), P.lds, s, dev, A, sep);
     return hipGetLastError();
+}
+
+// the fp64 FMAs of an exhaustive launch with A's strips and bands (roofline accounting)
+inline void march_fma(const ModelDev& dev, const MarchArgs& A, double* fma)
+{
+    const int Nw = dev.Nw, UJ = 2 * dev.ms - 1, S = 2 * Nw + 1;
+    double f = 0.0;
+    for (int b = 0; b < A.nbands; b++) {
+        const int rows = std::min(A.rows, (b + 1) * A.band_rows) - b * A.band_rows;
+        if (rows <= 0) continue;
+        const double steps = rows + 2 * Nw;
+        f += (double)A.nstrips * UJ * UJ * 64.0 * (steps * (dev.Na + S) + (double)rows * S);
+    }
+    *fma = f;
 }
 
 // one row chunk of the table; `fma`: the fp64 FMAs the launch executes (roofline accounting)
@@ -867,17 +885,8 @@ inline hipError_t launch_march(const ModelDev& dev, MarchArgs A, const Sep1D& se
         if (cost < best_cost - 1e-9) { best_cost = cost; best_nb = nb; }
     }
     { const char* e = getenv("UMPA_HIP_MARCH_BANDS"); if (e && atoi(e) > 0) best_nb = atoi(e); }
-    A.nbands = best_nb; A.band_rows = (A.rows + best_nb - 1) / best_nb;
-    if (fma) {
-        double f = 0.0;
-        for (int b = 0; b < A.nbands; b++) {
-            const int rows = std::min(A.rows, (b + 1) * A.band_rows) - b * A.band_rows;
-            if (rows <= 0) continue;
-            const double steps = rows + 2 * Nw;
-            f += (double)A.nstrips * UJ * UJ * 64.0 * (steps * (dev.Na + S) + (double)rows * S);
-        }
-        *fma = f;
-    }
+    if (A.nbands <= 0) { A.nbands = best_nb; A.band_rows = (A.rows + best_nb - 1) / best_nb; }   // (on-demand passes: the bands are the caller's tiles)
+    if (fma) march_fma(dev, A, fma);
     if (Nw == 6) return P.nxb == 4 ? launch_march_inst<6, 4>(dev, A, sep, P, s) : launch_march_inst<6, 8>(dev, A, sep, P, s);
     return P.nxb == 4 ? launch_march_inst<7, 4>(dev, A, sep, P, s) : launch_march_inst<7, 8>(dev, A, sep, P, s);
 }
@@ -953,7 +962,7 @@ inline bool od_enabled(int ntiles, int npass, bool masked)
 }
 
 // device scratch for `ntiles` tiles of `npass` passes and `npx` region pixels; fills the pointers of `od`
-#define UMPA_OD_NCNT (8 * (OD_ROUNDS + 1))                           // counters of a chunk: int[8] per stage
+#define UMPA_OD_NCNT (8 * OD_STAGES)                                 // counters of a chunk: int[8] per stage
 struct OdBuffers { int* tiles[2]; int* px[2]; int* counters; size_t zero_bytes; };
 
 inline int od_reserve(TiledState& st, int ntiles, int npass, size_t npx, OdArgs& od, OdBuffers& B)
@@ -1018,6 +1027,56 @@ inline hipError_t od_run_chunk(OdArgs od, const OdBuffers& B, hipStream_t s, Cor
     return hipSuccess;
 }
 
+// The same for corr_march, whose unit of work is (strip, band, pass) -- a "tile" is a strip x band, a pass NUY row offsets x every
+// column offset -- and whose walks all start at shift (0, 0): no seed tiles, the prediction is the walks themselves on a lattice
+// of sample pixels.
+//   0. the passes around row offset 0 (pc0 .. pc1), every tile: a static grid;
+//   1. the pixels of a lattice (every `sub`-th in both directions) walk; one that needs a pass that is not there parks and asks
+//      for it and its neighbours (od_park); OD_SAMPLE_ROUNDS rounds of  list -> table kernel over the list -> parked pixels again,
+//      then what the last round still asked for.  Their cost is 1 / sub^2 of a replay each; what they leave behind is `done`;
+//   2. every pixel walks (the lattice's again: they are 1 / sub^2 of the pixels); OD_ROUNDS repair rounds as in od_run_chunk,
+//      the last one computing every pass the tiles with parked pixels lack.
+template <class Corr, class Replay>
+inline hipError_t od_run_chunk_march(OdArgs od, const OdBuffers& B, hipStream_t s, Corr corr, Replay replay, int pc0, int pc1, int sub)
+{
+    hipError_t e = hipMemsetAsync(od.done, 0, B.zero_bytes, s);
+    if (e != hipSuccess) return e;
+    const int ntiles = od.ntx * od.nty, lb = (ntiles + 255) / 256;
+    od.r0 = od.c0 = -1;                                               // no seed tiles
+    od.nearest = 1;
+    auto stage = [&](int r) { return B.counters + 8 * r; };
+    int k = 0;                                                        // the stage whose counters were written last
+    auto round = [&](int what, bool walk) {
+        od.cnt_in = stage(k); od.cnt_out = stage(k + 1);
+        od.tile_in = B.tiles[k & 1]; od.tile_out = B.tiles[(k + 1) & 1];
+        od.px_in = B.px[k & 1]; od.px_out = B.px[(k + 1) & 1];
+        hipLaunchKernelGGL(od_list_kernel, dim3(lb), dim3(256), 0, s, od, what);
+        hipError_t re = hipGetLastError();
+        if (re != hipSuccess) return re;
+        od.mode = 2; if ((re = corr(od)) != hipSuccess) return re;
+        if (walk) { od.mode = 3; if ((re = replay(od)) != hipSuccess) return re; }
+        k++;
+        return hipSuccess;
+    };
+    od.cnt_in = nullptr; od.cnt_out = stage(0);
+    od.tile_in = nullptr; od.tile_out = B.tiles[0]; od.px_in = nullptr; od.px_out = B.px[0];
+    od.mode = 0; od.pass0 = pc0; od.npass_run = pc1 - pc0 + 1;
+    if ((e = corr(od)) != hipSuccess) return e;
+    od.pass0 = 0; od.npass_run = 0;
+    if (sub > 1) {
+        od.sub = sub; od.mode = 2; if ((e = replay(od)) != hipSuccess) return e;
+        for (int r = 1; r <= OD_SAMPLE_ROUNDS; r++) if ((e = round(2, true)) != hipSuccess) return e;
+        if ((e = round(2, false)) != hipSuccess) return e;            // (also clears the flags and requests of the last round's tiles)
+        od.sub = 0;
+        k++;                                                          // a fresh stage for the walks of every pixel
+        od.cnt_in = nullptr; od.cnt_out = stage(k);
+        od.tile_in = nullptr; od.tile_out = B.tiles[k & 1]; od.px_in = nullptr; od.px_out = B.px[k & 1];
+    }
+    od.mode = 2; if ((e = replay(od)) != hipSuccess) return e;
+    for (int r = 1; r <= OD_ROUNDS; r++) if ((e = round(r == OD_ROUNDS ? 3 : 2, true)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
 inline size_t tiled_table_budget()
 {
     const char* e = getenv("UMPA_HIP_TABLE_MB");
@@ -1069,14 +1128,16 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
     memset(&MP, 0, sizeof(MP));
     const char* march_baseA = nullptr; const char* march_baseB = nullptr;
     {
-        const char* od_env = getenv("UMPA_HIP_ONDEMAND");
-        const bool od_forced = od_env && atoi(od_env) != 0;           // (the on-demand stages are corr_volume's)
-        if (host_frames && march_wanted(Nw) && !od_forced) {
+        if (host_frames && march_wanted(Nw)) {
             MP = march_plan(Nw, UJ, K, N1d);
             if (MP.ok && !march_offsets(host_frames, K, dev.ref_mode ? -1 : 1, box, st.march_off_host, march_baseA, march_baseB)) MP.ok = false;
         }
     }
     if (MP.ok) N1p = MP.nstrips * MP.tw;                               // doubles per dense row and shift
+    // on-demand passes of corr_march (od_run_chunk_march): UMPA_HIP_ONDEMAND=1 on, =0 off
+    bool march_od = false;
+    { const char* od_env = getenv("UMPA_HIP_ONDEMAND"); if (od_env) march_od = atoi(od_env) != 0; }
+    march_od = march_od && MP.ok && MP.npass >= 3 && MP.npass <= 64 && !getenv("UMPA_HIP_ABLATE_MARCH");
     const size_t row_bytes = (size_t)UJ * UJ * N1p * sizeof(double);
     long rows_chunk = (long)(tiled_table_budget() / row_bytes) / UMPA_TILE * UMPA_TILE;
     if (rows_chunk < UMPA_TILE) rows_chunk = UMPA_TILE;
@@ -1183,6 +1244,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         CL.dry = false;
         const int ntiles = CL.ntx * CL.nty;
         const int* counts = nullptr;
+        double march_fma_full = 0.0;
 
         auto corr = [&](const OdArgs& od) {
             CL.od = od;
@@ -1198,10 +1260,18 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
                 MA.npa = MP.npa; MA.npb = MP.npb; MA.a_slot = MP.a_slot; MA.b_slot = MP.b_slot; MA.da = MP.da; MA.db = MP.db;
                 MA.baseA = march_baseA; MA.baseB = march_baseB; MA.frame_off = st.march_off;
                 { const char* ab = getenv("UMPA_HIP_ABLATE_MARCH"); MA.ablate = ab ? atoi(ab) : 0; }
+                MA.pass0 = 0; MA.npass_run = MP.npass;
+                if (od.done) {                                        // on-demand passes: the caller's bands, a part of the units
+                    MA.nbands = od.nty; MA.band_rows = od.tr;
+                    MA.done = od.done; MA.ndone = od.cnt0 ? od.cnt0 + OD_C_DONE : nullptr;
+                    if (od.mode == 2) { MA.items = od.items; MA.nitems = od.cnt_out + OD_C_ITEMS; }
+                    else if (od.npass_run > 0) { MA.pass0 = od.pass0; MA.npass_run = od.npass_run; }
+                }
                 double fma = 0.0;
                 tic(9);
                 ce = launch_march(dev, MA, st.sep, MP, s, &fma);
-                toc(fma);
+                if (!od.done) march_fma_full = fma;
+                toc(od.done ? 0.0 : fma);                             // (on-demand: counted from the device's tally, below)
                 return ce;
             }
             tic(3);
@@ -1213,6 +1283,8 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
             if (R.rows <= 0) return hipSuccess;
             dim3 blk(64, UMPA_REPLAY_ROWS), grd((A.N1 + 63) / 64, (R.rows + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
             if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);   // queue over the parked pixels
+            if (od.mode == 2 && od.sub > 1)                           // corr_march's sample lattice
+                grd = dim3(((A.N1 + od.sub - 1) / od.sub + 63) / 64, ((R.rows + od.sub - 1) / od.sub + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
             if (od.mode == 1) { blk = dim3(64, 1); grd = dim3((32 * od.tc + 63) / 64, od_seed_count(od.ntx, od.c0) * od_seed_count(od.nty, od.r0)); if (!grd.y) return hipSuccess; }
             static const int pad_lds = getenv("UMPA_HIP_REPLAY_PAD_LDS") ? atoi(getenv("UMPA_HIP_REPLAY_PAD_LDS")) : 0;   // diagnostics: occupancy
             tic(4);
@@ -1239,8 +1311,47 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         memset(&od, 0, sizeof(od));
         od.tc = CL.tc; od.ub = CL.ub; od.nbatch = CL.nbatch; od.npass = CL.npass; od.ntx = CL.ntx; od.nty = CL.nty;
         od.ub_inv = (65536 + CL.ub - 1) / CL.ub; od.nrow_inv = (65536 + CL.nrow - 1) / CL.nrow;
+        od.tr = UMPA_TILE;
         OdBuffers OB;
-        if (!MP.ok && od_enabled(ntiles, CL.npass, false) && !CA.ablate) {
+        int march_tiles = 0;
+        if (march_od) {                                               // tiles = strips x bands of about UMPA_HIP_MARCH_OD_ROWS rows
+            const char* bt = getenv("UMPA_HIP_MARCH_OD_ROWS");      // (read per match: the tests set it)
+            const int band_target = bt ? std::max(32, atoi(bt)) : 512;
+            const int nb = std::max(1, (drows + band_target / 2) / band_target);
+            od.tc = MP.wo; od.tr = (drows + nb - 1) / nb; od.ntx = MP.nstrips; od.nty = nb;
+            od.npass = MP.npass; od.nbatch = 1; od.ub = 64; od.ub_inv = 1024; od.nrow_inv = (65536 + MP.nuy - 1) / MP.nuy;
+            od.alone = 1;
+            march_tiles = od.ntx * od.nty;
+        }
+        if (march_od && march_tiles >= 2) {
+            if (od_reserve(st, march_tiles, MP.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
+            // the passes that hold the row offsets -1, 0, +1: where every walk starts
+            const char* se = getenv("UMPA_HIP_MARCH_OD_SUB");
+            const int sub = se ? atoi(se) : 8;
+            if ((e = od_run_chunk_march(od, OB, s, corr, replay, (ms - 2) / MP.nuy, std::min(MP.npass - 1, ms / MP.nuy), sub)) != hipSuccess) return (int)e;
+            int* slot = st.od_host + UMPA_OD_NCNT * (st.od_slot++ % UMPA_OD_SLOTS);
+            if ((e = hipMemcpyAsync(slot, OB.counters, UMPA_OD_NCNT * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+            counts = slot;
+            if (st.stat_n < 64) st.stat_slots[st.stat_n++] = slot;
+            if (getenv("UMPA_HIP_OD_DEBUG")) {                        // diagnostics: the stages' counters (a host wait)
+                (void)hipStreamSynchronize(s);
+                fprintf(stderr, "march on-demand: %d tiles (%d strips x %d bands of %d rows) x %d passes\n", march_tiles, od.ntx, od.nty, od.tr, MP.npass);
+                for (int r = 0; r < OD_STAGES; r++)
+                    fprintf(stderr, "  stage %2d: tiles listed %6d  pixels parked %8d  units listed %6d  units done (stage 0: all) %6d\n",
+                            r, slot[8 * r + OD_C_TILES], slot[8 * r + OD_C_PX], slot[8 * r + OD_C_ITEMS], slot[8 * r + OD_C_DONE]);
+            }
+            {   // the FMAs of one unit: an exhaustive launch's over its units (the bands are equal but for the last)
+                MarchArgs MF;
+                memset(&MF, 0, sizeof(MF));
+                MF.rows = drows; MF.nstrips = MP.nstrips; MF.npass = MP.npass; MF.nbands = od.nty; MF.band_rows = od.tr;
+                double f = 0.0;
+                march_fma(dev, MF, &f);
+                march_fma_full = f / ((double)march_tiles * MP.npass);
+            }
+            if (tt) for (auto it = tt->entries.rbegin(); it != tt->entries.rend(); ++it)
+                if (it->name == 9) { it->counts = counts; it->fma_per = march_fma_full; break; }
+            st.stat_total_passes += (double)march_tiles * MP.npass - (double)ntiles * CL.npass;   // (the sum below adds ntiles * CL.npass)
+        } else if (!MP.ok && od_enabled(ntiles, CL.npass, false) && !CA.ablate) {
             if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
             if ((e = od_run_chunk(od, OB, s, corr, replay)) != hipSuccess) return (int)e;
             // the counters of this chunk, for the FMA count of a timed match and for umpa_hip_last_stats
@@ -1478,6 +1589,7 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
         memset(&od, 0, sizeof(od));
         od.tc = CL.tc; od.ub = CL.ub; od.nbatch = CL.nbatch; od.npass = CL.npass; od.ntx = CL.ntx; od.nty = CL.nty;
         od.ub_inv = (65536 + CL.ub - 1) / CL.ub; od.nrow_inv = (65536 + CL.nrow - 1) / CL.nrow;
+        od.tr = UMPA_TILE;
         OdBuffers OB;
         if (od_enabled(ntiles, CL.npass, true) && !MA.ablate) {
             if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
