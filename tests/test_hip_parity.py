@@ -552,8 +552,12 @@ def test_on_demand_table_passes_change_nothing(hip_ns, monkeypatch, cfg):
     out, stats = {}, {}
     if "march_rows" in cfg:
         monkeypatch.setenv("UMPA_HIP_MARCH_OD_ROWS", str(cfg["march_rows"]))
-    for od in ("0", "1"):
-        monkeypatch.setenv("UMPA_HIP_ONDEMAND", od)
+    for od in ("0", "1", "lattice"):
+        # "lattice": corr_volume's / corr_masked's stages with the sample-lattice prediction (corr_march's only one) instead of seed tiles
+        if od == "lattice" and "march_rows" in cfg:
+            continue
+        monkeypatch.setenv("UMPA_HIP_ONDEMAND", "0" if od == "0" else "1")
+        monkeypatch.setenv("UMPA_HIP_OD_PRED", "lattice" if od == "lattice" else "seed")
         m = cls(sam, ref, mask_list=mask, window_size=cfg["Nw"], max_shift=cfg["ms"])
         m.assign_coordinates = cfg["assign"]
         m._force = _lib.F_FORCE_TILED
@@ -561,8 +565,9 @@ def test_on_demand_table_passes_change_nothing(hip_ns, monkeypatch, cfg):
         st = (ctypes.c_double * 4)()
         m._lib.check(m._lib.last_stats(m._handle, st), "last_stats")
         stats[od] = list(st)
-    for k in out["0"]:
-        assert np.array_equal(out["0"][k], out["1"][k], equal_nan=True), k
+    for od in out:
+        for k in out["0"]:
+            assert np.array_equal(out["0"][k], out[od][k], equal_nan=True), (od, k)
     assert stats["0"][0] == stats["0"][1] and stats["0"][2] == 0          # exhaustive: every unit, nothing parked
     if "march_rows" in cfg:
         # (strip, band, pass) units: a pass is two or three row offsets deep and every walk's 4 x 4 gather reaches two rows past its

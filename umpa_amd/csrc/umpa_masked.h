@@ -494,7 +494,9 @@ replay_cost_kernel(ModelDev m, const double* table, size_t slot_stride, int drow
     } else {
         if (!first) break;
         xj = blockIdx.x * 64 + threadIdx.x;
-        xi = row0 + blockIdx.y;
+        xi = blockIdx.y;
+        if (od.sub > 1) { xj = xj * od.sub + (od.sub >> 1); xi = xi * od.sub + (od.sub >> 1); }   // the sample lattice (od_run_chunk_lattice)
+        xi += row0;
         live = xi < row0 + rows && xj < A.N1;
     }
     const size_t px = (size_t)xi * A.pitch + xj;                        // in the output arrays
@@ -525,7 +527,7 @@ replay_cost_kernel(ModelDev m, const double* table, size_t slot_stride, int drow
             walk_feed(w, memo, st, c, fit, m.call_cap);
         }
         if (L.miss) od_park(od, L, xi * A.N1 + xj);
-        else {
+        else if (od.sub <= 1) {                                         // (the sample lattice's walks only predict: A.uv is read AND written)
             double nb[16];
             walk_finish(w, memo, m.subpx, nb);
             store_pixel(A, px, KIND, w, memo, nb);

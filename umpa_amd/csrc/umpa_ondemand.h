@@ -54,6 +54,7 @@ struct OdArgs {
     int sub;                          // replay mode 2: > 1 = only the pixels of a lattice, every sub-th in both directions (corr_march's
                                       // sample stage); 0, 1: every pixel
     int pass0, npass_run;             // corr_march, mode 0: the static grid computes these passes only (npass_run = 0: all)
+    unsigned long long central;       // od_run_chunk_lattice: the passes every tile gets before any walk (those around shift (0, 0))
     int alone;                        // 1: a parked pixel asks for the pass it missed alone, 0: and for its neighbours in the row-offset direction
     int r0, c0;                       // seed tiles: ty % OD_SP == r0 and tx % OD_SP == c0
     int ub_inv;                       // ceil(2^16 / ub): x / ub = (x * ub_inv) >> 16 for 0 <= x < 70
@@ -98,6 +99,7 @@ __device__ __forceinline__ void od_append(const OdArgs& od, int lin, unsigned lo
     }
 }
 
+// what = 4: the central passes of every tile (od_run_chunk_lattice).
 // what = 1, step 2: the predicted passes of the tiles that are not seed tiles, onto the work list.
 // what = 2, a repair round: the passes the missed tiles' parked pixels asked for; what = 3, the last round: every pass they lack.
 __global__ void __launch_bounds__(256)
@@ -105,6 +107,10 @@ od_list_kernel(OdArgs od, int what)
 {
     const int q = blockIdx.x * 256 + threadIdx.x;
     const unsigned long long all = od.npass >= 64 ? ~0ull : (1ull << od.npass) - 1;
+    if (what == 4) {                                                  // od_run_chunk_lattice, stage 0: the central passes of every tile
+        if (q < od.ntx * od.nty) od_append(od, q, od.central & all);
+        return;
+    }
     if (what >= 2) {
         if (q >= gp(od.cnt_in)[OD_C_TILES]) return;
         const int lin = gp(od.tile_in)[q];

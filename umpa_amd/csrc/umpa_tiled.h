@@ -501,7 +501,7 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         }
     }
     if (L.miss) od_park(od, L, xi * A.N1 + xj);
-    else {
+    else if (!(OD && od.sub > 1)) {                                   // (the sample lattice's walks only predict: A.uv is read AND written)
         double nb[16];
         walk_finish(w, memo, (R.ablate & 2) ? 0 : m.subpx, nb);
         if (KIND == 1 && (w.live.t != 0.0 || w.live.v != 0.0))      // eval_lookup left K in the v slot; (0,0) = never evaluated
@@ -1001,7 +1001,7 @@ inline hipError_t od_run_chunk(OdArgs od, const OdBuffers& B, hipStream_t s, Cor
     if (e != hipSuccess) return e;
     const int ntiles = od.ntx * od.nty, lb = (ntiles + 255) / 256;
     od.r0 = std::min(1, od.nty - 1); od.c0 = std::min(1, od.ntx - 1);
-    { static const char* pe = getenv("UMPA_HIP_OD_PRED"); od.nearest = pe ? atoi(pe) : 1; }   // tuning: 0 = union over the seed tiles around
+    { const char* pe = getenv("UMPA_HIP_OD_PRED"); od.nearest = pe && pe[0] == '0' ? 0 : 1; }   // tuning: 0 = union over the seed tiles around
     auto stage = [&](int r) { return B.counters + 8 * r; };
     // 1. seed tiles: every pass (a compact grid over them); their pixels record what they read
     od.cnt_in = nullptr; od.cnt_out = stage(0);
@@ -1027,17 +1027,18 @@ inline hipError_t od_run_chunk(OdArgs od, const OdBuffers& B, hipStream_t s, Cor
     return hipSuccess;
 }
 
-// The same for corr_march, whose unit of work is (strip, band, pass) -- a "tile" is a strip x band, a pass NUY row offsets x every
-// column offset -- and whose walks all start at shift (0, 0): no seed tiles, the prediction is the walks themselves on a lattice
-// of sample pixels.
-//   0. the passes around row offset 0 (pc0 .. pc1), every tile: a static grid;
+// The same without seed tiles: every walk starts at shift (0, 0), so the prediction can be the walks themselves on a lattice of
+// sample pixels.  For every table kernel; corr_march's unit of work is (strip, band, pass) -- a "tile" is a strip x band, a pass
+// NUY row offsets x every column offset.
+//   0. the passes around shift (0, 0) (od.central), every tile;
 //   1. the pixels of a lattice (every `sub`-th in both directions) walk; one that needs a pass that is not there parks and asks
-//      for it and its neighbours (od_park); OD_SAMPLE_ROUNDS rounds of  list -> table kernel over the list -> parked pixels again,
-//      then what the last round still asked for.  Their cost is 1 / sub^2 of a replay each; what they leave behind is `done`;
+//      for it (od_park); OD_SAMPLE_ROUNDS rounds of  list -> table kernel over the list -> parked pixels again,  then what
+//      the last round still asked for.  Their cost is 1 / sub^2 of a replay each; what they leave behind is `done`;
+//      (these walks store nothing: the start shifts A.uv are read AND written by a walk that ends);
 //   2. every pixel walks (the lattice's again: they are 1 / sub^2 of the pixels); OD_ROUNDS repair rounds as in od_run_chunk,
 //      the last one computing every pass the tiles with parked pixels lack.
 template <class Corr, class Replay>
-inline hipError_t od_run_chunk_march(OdArgs od, const OdBuffers& B, hipStream_t s, Corr corr, Replay replay, int pc0, int pc1, int sub)
+inline hipError_t od_run_chunk_lattice(OdArgs od, const OdBuffers& B, hipStream_t s, Corr corr, Replay replay, int sub)
 {
     hipError_t e = hipMemsetAsync(od.done, 0, B.zero_bytes, s);
     if (e != hipSuccess) return e;
@@ -1060,9 +1061,9 @@ inline hipError_t od_run_chunk_march(OdArgs od, const OdBuffers& B, hipStream_t 
     };
     od.cnt_in = nullptr; od.cnt_out = stage(0);
     od.tile_in = nullptr; od.tile_out = B.tiles[0]; od.px_in = nullptr; od.px_out = B.px[0];
-    od.mode = 0; od.pass0 = pc0; od.npass_run = pc1 - pc0 + 1;
-    if ((e = corr(od)) != hipSuccess) return e;
-    od.pass0 = 0; od.npass_run = 0;
+    hipLaunchKernelGGL(od_list_kernel, dim3(lb), dim3(256), 0, s, od, 4);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    od.mode = 2; if ((e = corr(od)) != hipSuccess) return e;
     if (sub > 1) {
         od.sub = sub; od.mode = 2; if ((e = replay(od)) != hipSuccess) return e;
         for (int r = 1; r <= OD_SAMPLE_ROUNDS; r++) if ((e = round(2, true)) != hipSuccess) return e;
@@ -1075,6 +1076,39 @@ inline hipError_t od_run_chunk_march(OdArgs od, const OdBuffers& B, hipStream_t 
     od.mode = 2; if ((e = replay(od)) != hipSuccess) return e;
     for (int r = 1; r <= OD_ROUNDS; r++) if ((e = round(r == OD_ROUNDS ? 3 : 2, true)) != hipSuccess) return e;
     return hipSuccess;
+}
+
+// the passes that hold the row and column offsets -1 .. +1 and the one further that every walk's 4 x 4 gather reaches
+// (Optim.cpp:41-130: rows / columns min - 1 .. min + 2 of the SHIFT; a pass is counted in offsets = sigma * shift)
+inline unsigned long long od_central_passes(int ms, int sigma, int nrow, int nbatch, int ub, int UJ)
+{
+    unsigned long long mask = 0;
+    const int lo = sigma > 0 ? -1 : -2, hi = sigma > 0 ? 2 : 1;
+    for (int oi = lo; oi <= hi; oi++)
+        for (int oj = lo; oj <= hi; oj++) {
+            const int ri = oi + ms - 1, rj = oj + ms - 1;
+            if (ri < 0 || ri >= UJ || rj < 0 || rj >= UJ) continue;
+            mask |= 1ull << ((ri / nrow) * nbatch + rj / ub);
+        }
+    return mask;
+}
+
+// which prediction the on-demand stages of corr_volume / corr_masked use: UMPA_HIP_OD_PRED = lattice | seed (default) | 0 (seed,
+// union over the seed tiles around); corr_march's is always the lattice
+inline bool od_lattice_wanted()
+{
+    const char* e = getenv("UMPA_HIP_OD_PRED");
+    return e && e[0] == 'l';                                          // (measured: the seed tiles predict corr_volume's and corr_masked's 32 x 32 tiles better)
+}
+inline int od_alone_wanted()                                         // 1: parked pixels ask for the missed pass alone (od_park)
+{
+    const char* e = getenv("UMPA_HIP_OD_ALONE");
+    return e ? atoi(e) : 1;
+}
+inline int od_lattice_sub(int fallback)
+{
+    const char* e = getenv("UMPA_HIP_OD_SUB");
+    return e ? atoi(e) : fallback;
 }
 
 inline size_t tiled_table_budget()
@@ -1265,7 +1299,6 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
                     MA.nbands = od.nty; MA.band_rows = od.tr;
                     MA.done = od.done; MA.ndone = od.cnt0 ? od.cnt0 + OD_C_DONE : nullptr;
                     if (od.mode == 2) { MA.items = od.items; MA.nitems = od.cnt_out + OD_C_ITEMS; }
-                    else if (od.npass_run > 0) { MA.pass0 = od.pass0; MA.npass_run = od.npass_run; }
                 }
                 double fma = 0.0;
                 tic(9);
@@ -1321,14 +1354,12 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
             od.tc = MP.wo; od.tr = (drows + nb - 1) / nb; od.ntx = MP.nstrips; od.nty = nb;
             od.npass = MP.npass; od.nbatch = 1; od.ub = 64; od.ub_inv = 1024; od.nrow_inv = (65536 + MP.nuy - 1) / MP.nuy;
             od.alone = 1;
+            od.central = od_central_passes(ms, dev.ref_mode ? -1 : 1, MP.nuy, 1, 64, UJ);
             march_tiles = od.ntx * od.nty;
         }
         if (march_od && march_tiles >= 2) {
             if (od_reserve(st, march_tiles, MP.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
-            // the passes that hold the row offsets -1, 0, +1: where every walk starts
-            const char* se = getenv("UMPA_HIP_MARCH_OD_SUB");
-            const int sub = se ? atoi(se) : 8;
-            if ((e = od_run_chunk_march(od, OB, s, corr, replay, (ms - 2) / MP.nuy, std::min(MP.npass - 1, ms / MP.nuy), sub)) != hipSuccess) return (int)e;
+            if ((e = od_run_chunk_lattice(od, OB, s, corr, replay, od_lattice_sub(8))) != hipSuccess) return (int)e;
             int* slot = st.od_host + UMPA_OD_NCNT * (st.od_slot++ % UMPA_OD_SLOTS);
             if ((e = hipMemcpyAsync(slot, OB.counters, UMPA_OD_NCNT * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
             counts = slot;
@@ -1353,7 +1384,12 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
             st.stat_total_passes += (double)march_tiles * MP.npass - (double)ntiles * CL.npass;   // (the sum below adds ntiles * CL.npass)
         } else if (!MP.ok && od_enabled(ntiles, CL.npass, false) && !CA.ablate) {
             if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
-            if ((e = od_run_chunk(od, OB, s, corr, replay)) != hipSuccess) return (int)e;
+            if (od_lattice_wanted()) {
+                od.alone = od_alone_wanted();
+                od.central = od_central_passes(ms, dev.ref_mode ? -1 : 1, CL.nrow, CL.nbatch, CL.ub, UJ);
+                e = od_run_chunk_lattice(od, OB, s, corr, replay, od_lattice_sub(4));
+            } else e = od_run_chunk(od, OB, s, corr, replay);
+            if (e != hipSuccess) return (int)e;
             // the counters of this chunk, for the FMA count of a timed match and for umpa_hip_last_stats
             int* slot = st.od_host + UMPA_OD_NCNT * (st.od_slot++ % UMPA_OD_SLOTS);
             if ((e = hipMemcpyAsync(slot, OB.counters, UMPA_OD_NCNT * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
@@ -1577,6 +1613,7 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
             if (rrows <= 0) return hipSuccess;
             dim3 blk(64), grd((A.N1 + 63) / 64, rrows);
             if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);
+            if (od.mode == 2 && od.sub > 1) grd = dim3(((A.N1 + od.sub - 1) / od.sub + 63) / 64, (rrows + od.sub - 1) / od.sub);   // the sample lattice
             if (od.mode == 1) { grd = dim3((32 * od.tc + 63) / 64, od_seed_count(od.ntx, od.c0) * od_seed_count(od.nty, od.r0)); if (!grd.y) return hipSuccess; }
             tic(7);
             if (kind == 1) hipLaunchKernelGGL((replay_cost_kernel<1>), grd, blk, 0, s, dev, (const double*)st.table, MA.slot_stride, drow0, N1d, xi_lo, rrows, A, od);
@@ -1593,7 +1630,12 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
         OdBuffers OB;
         if (od_enabled(ntiles, CL.npass, true) && !MA.ablate) {
             if (od_reserve(st, ntiles, CL.npass, (size_t)A.N0 * A.N1, od, OB)) return -3;
-            if ((e = od_run_chunk(od, OB, s, corr, replay)) != hipSuccess) return (int)e;
+            if (od_lattice_wanted()) {
+                od.alone = od_alone_wanted();
+                od.central = od_central_passes(ms, dev.ref_mode ? -1 : 1, CL.nrow, CL.nbatch, CL.ub, UJ);
+                e = od_run_chunk_lattice(od, OB, s, corr, replay, od_lattice_sub(4));
+            } else e = od_run_chunk(od, OB, s, corr, replay);
+            if (e != hipSuccess) return (int)e;
             int* slot = st.od_host + UMPA_OD_NCNT * (st.od_slot++ % UMPA_OD_SLOTS);
             if ((e = hipMemcpyAsync(slot, OB.counters, UMPA_OD_NCNT * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
             if (st.stat_n < 64) st.stat_slots[st.stat_n++] = slot;
