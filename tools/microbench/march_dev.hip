@@ -97,7 +97,7 @@ int main(int argc, char** argv)
     int nuy = Nw <= 5 ? 3 : 2;
     if (getenv("NUY")) nuy = atoi(getenv("NUY"));
     const int ncw = (nuy * UJ + 3) / 4, NT = ncw * 64;
-    A.nuy = nuy; A.npass = (UJ + nuy - 1) / nuy; A.pass0 = 0; A.npass_run = A.npass;
+    A.nuy = nuy; A.npass = (UJ + nuy - 1) / nuy;
     A.nstrips = nstrips;
     const int slots = 256 * (NT <= 512 ? 2 : 1);
     int nbands = nbands_arg > 0 ? nbands_arg : std::max(1, slots / (A.nstrips * A.npass));

@@ -58,7 +58,7 @@ struct MarchArgs {
     int ablate;               // diagnostics: 1 no DMA, 2 no frame loop, 4 no filters, 8 no stores
     // which (strip, band, pass) units the launch computes (on-demand passes, umpa_ondemand.h: a unit = a "tile" lin = band *
     // nstrips + strip and a pass):
-    //   items == nullptr: the static grid, every (strip, band) x the passes pass0 .. pass0 + npass_run - 1;
+    //   items == nullptr: the static grid, every (strip, band) x every pass;
     //   items != nullptr: the work list ((lin << 8) | pass), *nitems entries; the grid has a slot for every unit there could be
     //   and the workgroups past the list's end leave at once.
     // done / ndone (or null): the unit's bit is set in done[lin] and *ndone counted when its planes are written (read by later launches).
@@ -66,7 +66,6 @@ struct MarchArgs {
     const int* nitems;
     unsigned long long* done;
     int* ndone;
-    int pass0, npass_run;
 };
 
 template <int NW, int NXB>
@@ -130,8 +129,8 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
     } else {
         const int nitems = A.nstrips * A.nbands, per_xcd = (nitems + 7) >> 3;
         const int seq = blockIdx.x >> 3;
-        item = (blockIdx.x & 7) * per_xcd + seq / A.npass_run; pass = A.pass0 + seq % A.npass_run;
-        if (seq / A.npass_run >= per_xcd || item >= nitems) return;
+        item = (blockIdx.x & 7) * per_xcd + seq / A.npass; pass = seq % A.npass;
+        if (seq / A.npass >= per_xcd || item >= nitems) return;
     }
     const int strip = item % A.nstrips, band = item / A.nstrips;
     const int r_lo = band * A.band_rows, r_hi = min(A.rows, r_lo + A.band_rows);   // rows of this launch's chunk

@@ -53,7 +53,6 @@ struct OdArgs {
     int tr;                           // rows of a tile: 32 (corr_volume, corr_masked) or corr_march's band height (a tile = strip x band)
     int sub;                          // replay mode 2: > 1 = only the pixels of a lattice, every sub-th in both directions (corr_march's
                                       // sample stage); 0, 1: every pixel
-    int pass0, npass_run;             // corr_march, mode 0: the static grid computes these passes only (npass_run = 0: all)
     unsigned long long central;       // od_run_chunk_lattice: the passes every tile gets before any walk (those around shift (0, 0))
     int alone;                        // 1: a parked pixel asks for the pass it missed alone, 0: and for its neighbours in the row-offset direction
     int r0, c0;                       // seed tiles: ty % OD_SP == r0 and tx % OD_SP == c0

@@ -853,7 +853,7 @@ inline hipError_t launch_march_inst(const ModelDev& dev, const MarchArgs& A, con
     }
     const int nitems = A.nstrips * A.nbands;
     // (work list: a slot for every unit there could be; the workgroups past the list's end leave at once)
-    const int grid = A.items ? 8 * ((nitems * A.npass + 7) / 8) : 8 * ((nitems + 7) / 8) * A.npass_run;
+    const int grid = A.items ? 8 * ((nitems * A.npass + 7) / 8) : 8 * ((nitems + 7) / 8) * A.npass;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(UMPA_MARCH_NT), P.lds, s, dev, A, sep);
     return hipGetLastError();
 }
@@ -1294,7 +1294,6 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
                 MA.npa = MP.npa; MA.npb = MP.npb; MA.a_slot = MP.a_slot; MA.b_slot = MP.b_slot; MA.da = MP.da; MA.db = MP.db;
                 MA.baseA = march_baseA; MA.baseB = march_baseB; MA.frame_off = st.march_off;
                 { const char* ab = getenv("UMPA_HIP_ABLATE_MARCH"); MA.ablate = ab ? atoi(ab) : 0; }
-                MA.pass0 = 0; MA.npass_run = MP.npass;
                 if (od.done) {                                        // on-demand passes: the caller's bands, a part of the units
                     MA.nbands = od.nty; MA.band_rows = od.tr;
                     MA.done = od.done; MA.ndone = od.cnt0 ? od.cnt0 + OD_C_DONE : nullptr;
