@@ -326,12 +326,15 @@ def sharded(args, world, rank, local, dev, backend):
     stream = torch.cuda.current_stream().cuda_stream
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
-    # The slab is matched in four row pieces; as soon as the kernels of a piece are enqueued its rows start travelling
+    # The slab is matched in row pieces; as soon as the kernels of a piece are enqueued its rows start travelling
     # to rank 0 (one RCCL send/recv group per piece, behind the piece's kernels in stream order), so that the gather
     # overlaps the matching of the next piece instead of following the whole match.  UMPA_BENCH_GATHER=after: one gather
     # of the padded slabs after the match (sharding.gather_slabs), for comparison.
     overlap = os.environ.get("UMPA_BENCH_GATHER", "pieces") != "after"
-    piece_rows = ((-(-biggest // 4)) + 31) // 32 * 32                # the same on every rank
+    # six pieces of 192 rows at C4's 1022-row slabs: the last one (62 rows) is what the gather cannot overlap; the pieces cost the
+    # match 0.05 ms (tools/piece_rate.py: 1 piece 5.24 ms, 4: 5.27, 6: 5.32, 8: 5.42, 12: 5.59)
+    npieces = max(1, int(os.environ.get("UMPA_BENCH_PIECES", "6")))
+    piece_rows = ((-(-biggest // npieces)) + 31) // 32 * 32          # the same on every rank
     pending = []
 
     def on_rows(lo, hi, _user):
