@@ -206,6 +206,10 @@ struct ReplayArgs {
     int strip_w, tw, drows;   // strip_w > 0: the table is corr_march's, blocked by column strips of strip_w dense columns:
                               // [strip][drows][(2ms-1)^2][tw]; slot_stride = tw
     int row0, rows;           // OUTPUT rows [row0, row0+rows) whose dense rows the table holds
+    int bw_log2;              // the plain kernel (no on-demand stages): a wave walks a block of 2^bw_log2 x 2^(6 - bw_log2) pixels.
+                              // Round 4, late: 16 x 4 on corr_volume's table (C2: replay_walk 1.17 -> 0.91 ms; 32 x 2: 0.96, 8 x 8: 1.25),
+                              // 32 x 2 on corr_march's strip-blocked one (C3: 8.34 -> 7.78 ms; 16 x 4: 13.8) -- the walks of a block
+                              // share a smaller window of the maps and the table than those of 64 pixels in a row
     int ablate;               // diagnostics only (UMPA_HIP_ABLATE_REPLAY): 1 = 18 fixed lookups instead of the walk, 2 = no sub-pixel fit
 };
 
@@ -415,6 +419,16 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         if (!first) break;
         xj = blockIdx.x * 64 + threadIdx.x;
         xi = blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
+        if (!OD) {
+            // a wave = a block of 2^bw_log2 x 2^(6 - bw_log2) pixels (ReplayArgs): the window of the maps and of the table that
+            // its walks read is (rows + 2 ms) x (columns + 2 ms) positions -- 288 for 16 x 4 against 648 for 64 x 1 at C2
+            const int bwl = R.bw_log2;
+            // (blocks onto XCD-contiguous bands of block rows -- xcd_band_remap, as the table kernels do -- is slower: C2 0.90 -> 0.98 ms,
+            //  C3 7.7 -> 9.4)
+            const int bx = blockIdx.x, by = blockIdx.y;
+            xj = (bx << bwl) + (threadIdx.x & ((1 << bwl) - 1));
+            xi = ((by * UMPA_REPLAY_ROWS + threadIdx.y) << (6 - bwl)) + (threadIdx.x >> bwl);
+        }
         if (OD && od.sub > 1) { xj = xj * od.sub + (od.sub >> 1); xi = xi * od.sub + (od.sub >> 1); }   // the sample lattice (a compact grid)
         xi += R.row0;
         live = xi < R.row0 + R.rows && xj < A.N1;
@@ -1264,6 +1278,11 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         R.table = st.table; R.slot_stride = CA.slot_stride; R.drow0 = drow0; R.N1d = N1p;
         R.strip_w = 0; R.tw = 0; R.drows = drows;
         if (MP.ok) { R.strip_w = MP.wo; R.tw = MP.tw; R.slot_stride = (size_t)MP.tw; }
+        {
+            const char* be = getenv("UMPA_HIP_REPLAY_BW");           // tuning: 64, 32, 16, 8, 4
+            const int bw = be ? atoi(be) : (MP.ok ? 32 : 16);
+            R.bw_log2 = bw >= 64 ? 6 : bw >= 32 ? 5 : bw >= 16 ? 4 : bw >= 8 ? 3 : 2;
+        }
         R.row0 = xi_lo; R.rows = std::max(0, xi_hi - xi_lo);
         { const char* ab = getenv("UMPA_HIP_ABLATE_REPLAY"); R.ablate = ab ? atoi(ab) : 0; }
         // frame count as a template constant where the map planes are 32-bit addressable (eval_lookup)
@@ -1314,6 +1333,10 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         auto replay = [&](const OdArgs& od) {
             if (R.rows <= 0) return hipSuccess;
             dim3 blk(64, UMPA_REPLAY_ROWS), grd((A.N1 + 63) / 64, (R.rows + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
+            if (!od.mode) {                                           // (the plain kernel: blocks of 2^bw_log2 x 2^(6 - bw_log2) pixels per wave)
+                const int bw = 1 << R.bw_log2, bh = UMPA_REPLAY_ROWS * (64 >> R.bw_log2);
+                grd = dim3((A.N1 + bw - 1) / bw, (R.rows + bh - 1) / bh);
+            }
             if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);   // queue over the parked pixels
             if (od.mode == 2 && od.sub > 1)                           // corr_march's sample lattice
                 grd = dim3(((A.N1 + od.sub - 1) / od.sub + 63) / 64, ((R.rows + od.sub - 1) / od.sub + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
