@@ -420,8 +420,10 @@ __device__ __forceinline__ int xcd_band_remap(int lin, int total)
     return (lin & 7) * per + (lin >> 3);
 }
 
+#ifndef UMPA_DIRECT_BX
 #define UMPA_DIRECT_BX 64
 #define UMPA_DIRECT_BY 4
+#endif
 
 #define UMPA_WALK_THREADS (UMPA_DIRECT_BX * UMPA_DIRECT_BY)
 
@@ -471,7 +473,7 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
 // The general path with the windows served from LDS ("staged" direct kernel).
 //
 // match_direct reads every window element of every evaluation through the L1/TA path, which is what bounds it
-// (2.7 TB per C2 match at 51 of 64 B/clk/CU).  All windows a workgroup of 64 x 4 pixels can ever ask for lie in a
+// (2.7 TB per C2 match at 51 of 64 B/clk/CU).  All windows a workgroup of BX x BY pixels can ever ask for lie in a
 // fixed footprint: its pixel box widened by Nw for the stack whose window does not move and by Nw + max_shift - 1
 // for the one that does.  Here the workgroup runs the walk in lockstep: for every round of requests it goes through
 // the frames, stages the footprint of frame k (coalesced loads, once for all 256 lanes), and every lane sums its
@@ -479,12 +481,20 @@ match_direct_kernel(ModelDev m, RegionArgs A, int nbx, int nby)
 // Masks, per-frame positions and shapes, both coordinate conventions and steps work as there; the kernel-dark-field
 // model and footprints that do not fit LDS (large steps) stay on match_direct.
 // ------------------------------------------------------------------------------------------------
-#define UMPA_STAGED_BX 64
-#define UMPA_STAGED_BY 4
+// (round 4, late: a box of 16 x 16 pixels instead of 64 x 4 -- its footprint is 36 x 36 instead of 24 x 84 elements per frame at
+//  C2's window and search range, and a wave is a block of 16 x 4 pixels: C2's stack on this kernel 58.9 -> 52.4 ms, the 2 x 2
+//  sample-stepping stack 58.2 -> 50.9; match_direct keeps 64 x 4: at coarse steps and for the kernel-dark-field model the square
+//  box loses 8-20 %, profiles/r04_replay_blocks.txt)
+#ifndef UMPA_STAGED_BX
+#define UMPA_STAGED_BX 16
+#define UMPA_STAGED_BY 16
+#endif
 #define UMPA_STAGED_THREADS (UMPA_STAGED_BX * UMPA_STAGED_BY)
 #define UMPA_STAGED_TAIL 24          // fewer walking lanes than this (of 256): they finish without staging
-#define UMPA_STAGED_NR 8             // a footprint has at most NR * BY = 32 rows ...
-#define UMPA_STAGED_NC 2             // ... and NC * BX = 128 columns (staged_geometry sends anything larger to match_direct)
+#ifndef UMPA_STAGED_NR
+#define UMPA_STAGED_NR 3             // a footprint has at most NR * BY = 48 rows ...
+#define UMPA_STAGED_NC 3             // ... and NC * BX = 48 columns (staged_geometry sends anything larger to match_direct)
+#endif
 
 struct StagedGeom {
     int hq, hr, hm;                  // halo of the sample / reference / mask footprint around the pixel box
