@@ -496,6 +496,10 @@ replay_cost_kernel(ModelDev m, const double* table, size_t slot_stride, int drow
         xj = blockIdx.x * 64 + threadIdx.x;
         xi = blockIdx.y;
         if (od.sub > 1) { xj = xj * od.sub + (od.sub >> 1); xi = xi * od.sub + (od.sub >> 1); }   // the sample lattice (od_run_chunk_lattice)
+        else {                                                          // a wave = a block of 16 x 4 pixels (as replay_walk, ReplayArgs::bw_log2)
+            xj = (blockIdx.x << 4) + (threadIdx.x & 15);
+            xi = (blockIdx.y << 2) + (threadIdx.x >> 4);
+        }
         xi += row0;
         live = xi < row0 + rows && xj < A.N1;
     }

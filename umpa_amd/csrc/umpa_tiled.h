@@ -417,19 +417,18 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         live = live && xi >= R.row0 && xi < R.row0 + R.rows && xj < A.N1;
     } else {
         if (!first) break;
-        xj = blockIdx.x * 64 + threadIdx.x;
-        xi = blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y;
-        if (!OD) {
+        if (OD && od.sub > 1) {                                      // the sample lattice (a compact grid, 64 lattice pixels of a row per wave)
+            xj = (blockIdx.x * 64 + threadIdx.x) * od.sub + (od.sub >> 1);
+            xi = (blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y) * od.sub + (od.sub >> 1);
+        } else {
             // a wave = a block of 2^bw_log2 x 2^(6 - bw_log2) pixels (ReplayArgs): the window of the maps and of the table that
-            // its walks read is (rows + 2 ms) x (columns + 2 ms) positions -- 288 for 16 x 4 against 648 for 64 x 1 at C2
-            const int bwl = R.bw_log2;
+            // its walks read is (rows + 2 ms) x (columns + 2 ms) positions -- 288 for 16 x 4 against 648 for 64 x 1 at C2.
             // (blocks onto XCD-contiguous bands of block rows -- xcd_band_remap, as the table kernels do -- is slower: C2 0.90 -> 0.98 ms,
             //  C3 7.7 -> 9.4)
-            const int bx = blockIdx.x, by = blockIdx.y;
-            xj = (bx << bwl) + (threadIdx.x & ((1 << bwl) - 1));
-            xi = ((by * UMPA_REPLAY_ROWS + threadIdx.y) << (6 - bwl)) + (threadIdx.x >> bwl);
+            const int bwl = R.bw_log2;
+            xj = (blockIdx.x << bwl) + (threadIdx.x & ((1 << bwl) - 1));
+            xi = ((blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y) << (6 - bwl)) + (threadIdx.x >> bwl);
         }
-        if (OD && od.sub > 1) { xj = xj * od.sub + (od.sub >> 1); xi = xi * od.sub + (od.sub >> 1); }   // the sample lattice (a compact grid)
         xi += R.row0;
         live = xi < R.row0 + R.rows && xj < A.N1;
     }
@@ -1333,7 +1332,7 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
         auto replay = [&](const OdArgs& od) {
             if (R.rows <= 0) return hipSuccess;
             dim3 blk(64, UMPA_REPLAY_ROWS), grd((A.N1 + 63) / 64, (R.rows + UMPA_REPLAY_ROWS - 1) / UMPA_REPLAY_ROWS);
-            if (!od.mode) {                                           // (the plain kernel: blocks of 2^bw_log2 x 2^(6 - bw_log2) pixels per wave)
+            if (od.mode == 0 || od.mode == 2) {                       // (every pixel: blocks of 2^bw_log2 x 2^(6 - bw_log2) pixels per wave)
                 const int bw = 1 << R.bw_log2, bh = UMPA_REPLAY_ROWS * (64 >> R.bw_log2);
                 grd = dim3((A.N1 + bw - 1) / bw, (R.rows + bh - 1) / bh);
             }
@@ -1633,7 +1632,7 @@ inline int tiled_match_masked(TiledState& st, const ModelDev& dev, int kind, int
         };
         auto replay = [&](const OdArgs& od) {
             if (rrows <= 0) return hipSuccess;
-            dim3 blk(64), grd((A.N1 + 63) / 64, rrows);
+            dim3 blk(64), grd((A.N1 + 15) / 16, (rrows + 3) / 4);           // blocks of 16 x 4 pixels (modes 0 and 2)
             if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);
             if (od.mode == 2 && od.sub > 1) grd = dim3(((A.N1 + od.sub - 1) / od.sub + 63) / 64, (rrows + od.sub - 1) / od.sub);   // the sample lattice
             if (od.mode == 1) { grd = dim3((32 * od.tc + 63) / 64, od_seed_count(od.ntx, od.c0) * od_seed_count(od.nty, od.r0)); if (!grd.y) return hipSuccess; }
