@@ -553,13 +553,16 @@ __device__ __forceinline__ void corr_volume_tile(const ModelDev& m, const CorrAr
 }
 
 // (tile, pass) of a workgroup of a static grid: the passes of a tile on consecutive slots of ONE XCD (blocks b, b+8, ...
-// share an XCD), so that their re-reads of the tile's patches are served by that XCD's L2.  Placement only affects speed.
+// share an XCD), so that their re-reads of the tile's patches are served by that XCD's L2; the TILES go to the XCDs in turn
+// (round 4, late: until then every XCD had a contiguous band of tiles -- neighbouring tiles on eight L2s instead of one: C2
+// corr_volume 1.28 -> 1.23 ms, one rank's slab of C4 2.62 -> 2.46; the passes of a tile on different XCDs as well: 1.37).
+// Placement only affects speed.
 // od.mode 0: every pass of every tile; 3: a compact grid over the seed tiles (umpa_ondemand.h).
 __device__ __forceinline__ bool od_static_item(const OdCorr& od, int ntx, int ntiles, int npass, int& lin, int& pass)
 {
     const int nt = od.mode == 3 ? od.nseed : ntiles, tiles_per_xcd = (nt + 7) >> 3;
     const int seq = blockIdx.x >> 3;                                  // position in this XCD's queue
-    const int t = (blockIdx.x & 7) * tiles_per_xcd + seq / npass;     // contiguous band of tiles per XCD
+    const int t = (seq / npass) * 8 + (blockIdx.x & 7);               // tile 8 q + x on XCD x
     pass = seq % npass;
     if (seq / npass >= tiles_per_xcd || t >= nt) return false;
     lin = od.mode == 3 ? (od.r0 + (t / od.nsx) * OD_SP) * ntx + od.c0 + (t % od.nsx) * OD_SP : t;

@@ -129,7 +129,7 @@ corr_march_kernel(ModelDev m, MarchArgs A, Sep1D sep)
     } else {
         const int nitems = A.nstrips * A.nbands, per_xcd = (nitems + 7) >> 3;
         const int seq = blockIdx.x >> 3;
-        item = (blockIdx.x & 7) * per_xcd + seq / A.npass; pass = seq % A.npass;
+        item = (blockIdx.x & 7) * per_xcd + seq / A.npass; pass = seq % A.npass;   // (items to the XCDs in turn instead: no difference, C3 26.6 / 26.3 ms)
         if (seq / A.npass >= per_xcd || item >= nitems) return;
     }
     const int strip = item % A.nstrips, band = item / A.nstrips;

@@ -81,7 +81,7 @@ prep_maps_kernel(ModelDev m, Maps M, Sep1D sep, int ntx, int nty, int sides, int
     double* raw = reinterpret_cast<double*>(smem_raw);
     double* hpl = raw + C::RAW;                            // 2 planes: H-filtered values, H-filtered squares
 
-    const int lin = xcd_band_remap(blockIdx.x, ntx * nty);
+    const int lin = xcd_band_remap(blockIdx.x, ntx * nty);            // (tiles to the XCDs in turn instead: C2 0.374 -> 0.364 ms, but 0.70-0.75 -> 0.81 on a slab of C4)
     if (lin >= ntx * nty) return;
     const int tx = tx0 + lin % ntx, ty = ty0 + lin / ntx;              // (tx0, ty0): first tile of the rectangle the match needs
     // outputs live on x in [NW, H-NW) x [NW, W-NW); this tile's first output pixel:
@@ -424,8 +424,8 @@ replay_walk_kernel(ModelDev m, Maps M, ReplayArgs R, RegionArgs A, OdArgs od_in)
         } else {
             // a wave = a block of 2^bw_log2 x 2^(6 - bw_log2) pixels (ReplayArgs): the window of the maps and of the table that
             // its walks read is (rows + 2 ms) x (columns + 2 ms) positions -- 288 for 16 x 4 against 648 for 64 x 1 at C2.
-            // (blocks onto XCD-contiguous bands of block rows -- xcd_band_remap, as the table kernels do -- is slower: C2 0.90 -> 0.98 ms,
-            //  C3 7.7 -> 9.4)
+            // (blocks onto XCD-contiguous bands of block rows -- xcd_band_remap -- is slower: C2 0.90 -> 0.98 ms, C3 7.7 -> 9.4; so are
+            //  XCD-contiguous strips of block columns: 0.91 -> 1.08; see the grid's width at the launch)
             const int bwl = R.bw_log2;
             xj = (blockIdx.x << bwl) + (threadIdx.x & ((1 << bwl) - 1));
             xi = ((blockIdx.y * UMPA_REPLAY_ROWS + threadIdx.y) << (6 - bwl)) + (threadIdx.x >> bwl);
@@ -1336,10 +1336,18 @@ inline int tiled_match(TiledState& st, const ModelDev& dev, int kind, int H, int
             if (od.mode == 0 || od.mode == 2) {                       // (every pixel: blocks of 2^bw_log2 x 2^(6 - bw_log2) pixels per wave)
                 const int bw = 1 << R.bw_log2, bh = UMPA_REPLAY_ROWS * (64 >> R.bw_log2);
                 grd = dim3((A.N1 + bw - 1) / bw, (R.rows + bh - 1) / bh);
-                // workgroups go to the XCDs in turn: with a multiple of 8 blocks per grid row a block and the ones above and below it, which
-                // read much the same lines, meet in ONE XCD's L2 -- and eight L2s serve them faster than one (profiles/r04_replay_blocks.txt:
-                // strips of block columns per XCD 0.91 -> 1.08 ms; region width 2048: 0.230 -> 0.218 ns per pixel with one idle block more per row)
-                if ((grd.x & 7) == 0) grd.x += 1;
+                // Workgroups go to the XCDs in turn: with a multiple of 8 blocks per grid row a block and the ones above and below it,
+                // which read much the same rows of the maps, meet in ONE XCD's L2.  Whether that is good depends on how much they share
+                // (profiles/r04_replay_blocks.txt): at C2 (28 KB of map window per block) eight L2s serve them faster than one -- 0.967
+                // against 0.916 ms --, at C3 (130 KB per block: 20 frames, +-7 shifts) the lines fetched eight times over are what
+                // counts -- 7.8 against 13.2 ms.  So: a multiple of 8 for large windows, never one for small ones (idle blocks on the right).
+                {
+                    const size_t window = (size_t)(bh + 2 * ms) * (bw + 2 * ms) * (((size_t)K + 1) / 2 * 16 + 16);
+                    const char* ge = getenv("UMPA_HIP_REPLAY_GRIDX");                 // tuning: 1 never a multiple of 8, 2 always
+                    const int gx = ge ? atoi(ge) : (kind == 1 && window > 65536 ? 2 : 1);
+                    if (gx == 1 && (grd.x & 7) == 0) grd.x += 1;
+                    if (gx == 2) grd.x = (grd.x + 7) / 8 * 8;
+                }
             }
             if (od.mode == 3) grd = dim3(2 * device_cu_count(), 1);   // queue over the parked pixels
             if (od.mode == 2 && od.sub > 1)                           // corr_march's sample lattice
